@@ -1,0 +1,591 @@
+// bf16 flash attention for gfx950: softmax(QKᵀ/√dh)·V, non-causal, no mask, dropout 0
+// (SiglipAttention, TF:models/siglip/modeling_siglip.py:273-306; softmax in fp32 as in :241).
+// v_mfma_f32_32x32x16_bf16 throughout, 64-lane wavefronts, 4 waves per workgroup, each wave owns 32 rows.
+//
+// Layouts: q,k,v head-major [B][H][N][DP] (DP = head_dim rounded up to 16; pad columns are zero), written by
+// the QKV GEMM epilogue; out / dout token-major [B*N][H*dh]; dqkv token-major [B*N][3*H*dh].
+//
+// Forward ("query on the lane"): Sᵀ = K·Qᵀ so each lane owns one query column and 16 of a 32-key block's scores;
+// the row max / row sum are lane-local plus one cross-half shuffle, the running rescale factor is a per-lane
+// scalar, and Oᵀ = Vᵀ·Pᵀ consumes the Sᵀ accumulator registers directly as the MFMA B operand (no LDS round
+// trip for P).  Vᵀ fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16.
+// Backward recomputes P from the saved log-sum-exp.  Two kernels, no atomics, bitwise reproducible:
+//   kv-kernel ("key on the lane"):  S = Q·Kᵀ, dP = dO·Vᵀ, dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS   (wave owns 32 keys)
+//   q-kernel  ("query on the lane"): Sᵀ = K·Qᵀ, dPᵀ = V·dOᵀ, dQᵀ += Kᵀ·dSᵀ             (wave owns 32 queries)
+//
+// Roofline: MFMA-bound; algorithmic FLOPs fwd 4·N²·dh per (b,h), bwd 10·N²·dh (the two-kernel split executes
+// 14·N²·dh; the extra recompute buys determinism and no dQ atomics).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sgl {
+
+hipError_t attn_ref_fwd(const float*, const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
+hipError_t attn_ref_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                        float*, int, int, int, int, int, hipStream_t);
+
+template <int DP>
+struct AttnCfg {
+  static constexpr int KS = DP / 16;          // MFMA k-steps across the head dim
+  static constexpr int DT = (DP + 31) / 32;   // 32-wide head-dim tiles of the output
+  static constexpr int CPR = DP / 8;          // 16-byte chunks per row
+  static constexpr int RSTR = DP * 2 + 16;    // row-read image stride: odd multiple of 16 B -> b128 conflict-free
+  static constexpr int TSTR = 192;            // transposed-read image stride: 4 rows x 64 B cover all 64 banks
+  static constexpr int DSTR = 208;            // dual-use image (row reads + transposed reads), 96 columns
+};
+
+__device__ __forceinline__ u32x4 a_ldg(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 lds_row8(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x4 lds_tr4(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SGL_LDS bf16x4*)(p));
+}
+// A-operand fragment of Xᵀ for a 32x32x16 MFMA whose B operand is an accumulator tile: element j of lane half h
+// is row 16*kk + 8*(j>>2) + 4*h + (j&3) of the row-major LDS image, column = d0 + (lane & 31).
+__device__ __forceinline__ bf16x8 lds_trfrag(const char* img, int stride, int kk, int dcol0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const char* a = img + (16 * kk + 4 * (g >> 1) + q) * stride + (dcol0 + 16 * (g & 1) + 4 * p) * 2;
+  const bf16x4 lo = lds_tr4(a);
+  const bf16x4 hi = lds_tr4(a + 8 * stride);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)s[base + j];
+  return r;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ======================================================================================================
+// forward
+// ======================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int H, int N, int dh, float c,
+                                                          float scale) {
+  using C = AttnCfg<DP>;
+  constexpr int KT = 64;
+  constexpr int KBYTES = KT * C::RSTR, VBYTES = KT * C::TSTR, STAGE = KBYTES + VBYTES;
+  constexpr int NCH = KT * C::CPR, NQ = (NCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const size_t mat = (size_t)bh * N * DP;
+  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
+
+  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+  const int qi = lane & 31, hh = lane >> 5;
+  bf16x8 qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks)
+    qf[ks] = as_bf16x8(a_ldg(rq, (q0 + qi < N) ? (uint32_t)(((q0 + qi) * DP + 16 * ks + 8 * hh) * 2) : SGL_OOB));
+
+  u32x4 sk[NQ], sv[NQ];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ch = t + q * 256;
+      const uint32_t off = (ch < NCH) ? (uint32_t)(tile * KT * DP * 2 + ch * 16) : SGL_OOB;
+      sk[q] = a_ldg(rk, off);
+      sv[q] = a_ldg(rv, off);
+    }
+  };
+  auto store_stage = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ch = t + q * 256;
+      if (ch < NCH) {
+        const int row = ch / C::CPR, cc = ch - row * C::CPR;
+        *reinterpret_cast<u32x4*>(base + row * C::RSTR + cc * 16) = sk[q];
+        *reinterpret_cast<u32x4*>(base + KBYTES + row * C::TSTR + cc * 16) = sv[q];
+      }
+    }
+  };
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  __syncthreads();  // zero fill done
+  store_stage(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int cur = tile & 1;
+    if (tile + 1 < ntiles) load_tile(tile + 1);
+    const char* kb = smem + cur * STAGE;
+    const char* vb = kb + KBYTES;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const bf16x8 k0 = lds_row8(kb + qi * C::RSTR + (16 * ks + 8 * hh) * 2);
+      const bf16x8 k1 = lds_row8(kb + (qi + 32) * C::RSTR + (16 * ks + 8 * hh) * 2);
+      s0 = MFMA32(k0, qf[ks], s0);
+      s1 = MFMA32(k1, qf[ks], s1);
+    }
+    if (tile == ntiles - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = tile * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= N) s0[r] = -INFINITY;
+        if (key + 32 >= N) s1[r] = -INFINITY;
+      }
+    }
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = fast_exp2(c * (m_run - m_new));
+    const float mc = m_new * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = fast_exp2(fmaf(s0[r], c, -mc));
+      s1[r] = fast_exp2(fmaf(s1[r], c, -mc));
+      rs += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    bf16x8 pb[4];
+    pb[0] = pack8(s0, 0);
+    pb[1] = pack8(s0, 8);
+    pb[2] = pack8(s1, 0);
+    pb[3] = pack8(s1, 8);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) o[dt] = MFMA32(lds_trfrag(vb, C::TSTR, kk, dt * 32, lane), pb[kk], o[dt]);
+    if (tile + 1 < ntiles) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+  const float l = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l;
+  const int q = q0 + qi;
+  if (q < N) {
+    bf16* orow = out + ((size_t)b * N + q) * ((size_t)H * dh) + hd * dh;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * hh;
+        if (d < dh) {
+          bf16x4 v4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v4[r] = (bf16)(o[dt][4 * g4 + r] * inv);
+          *reinterpret_cast<bf16x4*>(orow + d) = v4;
+        }
+      }
+    if (hh == 0) lse[(size_t)bh * N + q] = m_run * scale + __logf(l);
+  }
+}
+
+// ======================================================================================================
+// backward: delta = rowsum(dO ∘ O)
+// ======================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO,
+                                                         float* __restrict__ delta, int B, int H, int N, int dh) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)B * N * H;
+  if (idx >= total) return;
+  const int h = (int)(idx % H);
+  const size_t tok = idx / H;  // b*N + i
+  const int b = (int)(tok / N), i = (int)(tok - (size_t)b * N);
+  const bf16* o = O + tok * ((size_t)H * dh) + h * dh;
+  const bf16* d = dO + tok * ((size_t)H * dh) + h * dh;
+  float acc = 0.f;
+  for (int j = 0; j < dh; j += 8) {
+    float a[8], g[8];
+    Vec<bf16, 8>::ld(o + j, a);
+    Vec<bf16, 8>::ld(d + j, g);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc = fmaf(a[r], g[r], acc);
+  }
+  delta[((size_t)b * H + h) * N + i] = acc;
+}
+
+// ======================================================================================================
+// backward: dK, dV   (wave owns 32 keys; sweeps 32-query tiles staged in LDS)
+// ======================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                             const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                             const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                             int B, int H, int N, int dh, float c, float scale) {
+  using C = AttnCfg<DP>;
+  constexpr int QT = 32;
+  constexpr int IMG = QT * C::DSTR;            // one dual-use image
+  constexpr int STAGE = 2 * IMG + 2 * QT * 4;  // Q image, dO image, lse[32], delta[32]
+  constexpr int NCH = QT * C::CPR, NQ = (NCH + 255) / 256;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+  const int D = H * dh;
+  const int key0 = blockIdx.x * 128 + w * 32;
+  const size_t mat = (size_t)bh * N * DP;
+  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
+  const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
+
+  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+  const int li = lane & 31, hh = lane >> 5;
+  bf16x8 kfr[C::KS], vfr[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const uint32_t off = (key0 + li < N) ? (uint32_t)(((key0 + li) * DP + 16 * ks + 8 * hh) * 2) : SGL_OOB;
+    kfr[ks] = as_bf16x8(a_ldg(rk, off));
+    vfr[ks] = as_bf16x8(a_ldg(rv, off));
+  }
+
+  u32x4 sq[NQ], sd[NQ];
+  float s_l = 0.f, s_d = 0.f;
+  auto load_tile = [&](int qt) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ch = t + q * 256;
+      const int row = ch / C::CPR, cc = ch - row * C::CPR;
+      const int qrow = qt * QT + row;
+      const bool ok = (ch < NCH) && (qrow < N);
+      sq[q] = a_ldg(rq, ok ? (uint32_t)((qrow * DP + cc * 8) * 2) : SGL_OOB);
+      sd[q] = a_ldg(rdo, (ok && cc * 8 < dh) ? (uint32_t)(((size_t)qrow * D + cc * 8) * 2) : SGL_OOB);
+    }
+    if (t < QT) {
+      const int qrow = qt * QT + t;
+      s_l = (qrow < N) ? lse[(size_t)bh * N + qrow] * LOG2E : INFINITY;
+      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] : 0.f;
+    }
+  };
+  auto store_stage = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ch = t + q * 256;
+      if (ch < NCH) {
+        const int row = ch / C::CPR, cc = ch - row * C::CPR;
+        *reinterpret_cast<u32x4*>(base + row * C::DSTR + cc * 16) = sq[q];
+        *reinterpret_cast<u32x4*>(base + IMG + row * C::DSTR + cc * 16) = sd[q];
+      }
+    }
+    if (t < QT) {
+      reinterpret_cast<float*>(base + 2 * IMG)[t] = s_l;
+      reinterpret_cast<float*>(base + 2 * IMG + QT * 4)[t] = s_d;
+    }
+  };
+
+  f32x16 dk[C::DT], dv[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  const int ntiles = (N + QT - 1) / QT;
+  load_tile(0);
+  __syncthreads();
+  store_stage(0);
+  __syncthreads();
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int cur = qt & 1;
+    if (qt + 1 < ntiles) load_tile(qt + 1);
+    const char* qimg = smem + cur * STAGE;
+    const char* dimg = qimg + IMG;
+    const float* lrow = reinterpret_cast<const float*>(qimg + 2 * IMG);
+    const float* drow = lrow + QT;
+    f32x16 S, dP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const bf16x8 qa = lds_row8(qimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
+      const bf16x8 da = lds_row8(dimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
+      S = MFMA32(qa, kfr[ks], S);
+      dP = MFMA32(da, vfr[ks], dP);
+    }
+    // S[r], dP[r]: query row (r&3) + 8*(r>>2) + 4*hh of the tile, key = lane & 31
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(lrow + 8 * g4 + 4 * hh);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(drow + 8 * g4 + 4 * hh);
+#pragma unroll
+      for (int r3 = 0; r3 < 4; ++r3) {
+        const int r = 4 * g4 + r3;
+        const float p = fast_exp2(fmaf(S[r], c, -L4[r3]));
+        S[r] = p;
+        dP[r] = p * (dP[r] - D4[r3]) * scale;
+      }
+    }
+    bf16x8 pb[2], dsb[2];
+    pb[0] = pack8(S, 0);
+    pb[1] = pack8(S, 8);
+    dsb[0] = pack8(dP, 0);
+    dsb[1] = pack8(dP, 8);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        dv[dt] = MFMA32(lds_trfrag(dimg, C::DSTR, kk, dt * 32, lane), pb[kk], dv[dt]);
+        dk[dt] = MFMA32(lds_trfrag(qimg, C::DSTR, kk, dt * 32, lane), dsb[kk], dk[dt]);
+      }
+    if (qt + 1 < ntiles) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+  const int key = key0 + li;
+  if (key < N) {
+    bf16* krow = dqkv + ((size_t)b * N + key) * (3 * (size_t)D) + D + hd * dh;
+    bf16* vrow = krow + D;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * hh;
+        if (d < dh) {
+          bf16x4 a, g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a[r] = (bf16)dk[dt][4 * g4 + r];
+            g[r] = (bf16)dv[dt][4 * g4 + r];
+          }
+          *reinterpret_cast<bf16x4*>(krow + d) = a;
+          *reinterpret_cast<bf16x4*>(vrow + d) = g;
+        }
+      }
+  }
+}
+
+// ======================================================================================================
+// backward: dQ   (wave owns 32 queries; sweeps 32-key tiles staged in LDS)
+// ======================================================================================================
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                            int B, int H, int N, int dh, float c, float scale) {
+  using C = AttnCfg<DP>;
+  constexpr int KT = 32;
+  constexpr int KIMG = KT * C::DSTR, VIMG = KT * C::RSTR, STAGE = KIMG + VIMG;
+  constexpr int NCH = KT * C::CPR, NQ = (NCH + 255) / 256;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+  const int D = H * dh;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const size_t mat = (size_t)bh * N * DP;
+  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
+  const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
+  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
+
+  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+
+  const int li = lane & 31, hh = lane >> 5;
+  const int q = q0 + li;
+  bf16x8 qf[C::KS], dof[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int col = 16 * ks + 8 * hh;
+    qf[ks] = as_bf16x8(a_ldg(rq, (q < N) ? (uint32_t)((q * DP + col) * 2) : SGL_OOB));
+    dof[ks] = as_bf16x8(a_ldg(rdo, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
+  }
+  const float Lq = (q < N) ? lse[(size_t)bh * N + q] * LOG2E : INFINITY;
+  const float Dq = (q < N) ? delta[(size_t)bh * N + q] : 0.f;
+
+  u32x4 sk[NQ], sv[NQ];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int ch = t + qq * 256;
+      const uint32_t off = (ch < NCH) ? (uint32_t)(kt * KT * DP * 2 + ch * 16) : SGL_OOB;
+      sk[qq] = a_ldg(rk, off);
+      sv[qq] = a_ldg(rv, off);
+    }
+  };
+  auto store_stage = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      const int ch = t + qq * 256;
+      if (ch < NCH) {
+        const int row = ch / C::CPR, cc = ch - row * C::CPR;
+        *reinterpret_cast<u32x4*>(base + row * C::DSTR + cc * 16) = sk[qq];
+        *reinterpret_cast<u32x4*>(base + KIMG + row * C::RSTR + cc * 16) = sv[qq];
+      }
+    }
+  };
+
+  f32x16 dq[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  __syncthreads();
+  store_stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const char* kimg = smem + cur * STAGE;
+    const char* vimg = kimg + KIMG;
+    f32x16 S, dP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const bf16x8 ka = lds_row8(kimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
+      const bf16x8 va = lds_row8(vimg + li * C::RSTR + (16 * ks + 8 * hh) * 2);
+      S = MFMA32(ka, qf[ks], S);
+      dP = MFMA32(va, dof[ks], dP);
+    }
+    // S[r], dP[r]: key row (r&3) + 8*(r>>2) + 4*hh of the tile, query = lane & 31
+    const bool last = (kt == ntiles - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float p = fast_exp2(fmaf(S[r], c, -Lq));
+      if (last && key >= N) p = 0.f;
+      dP[r] = p * (dP[r] - Dq) * scale;
+    }
+    bf16x8 dsb[2];
+    dsb[0] = pack8(dP, 0);
+    dsb[1] = pack8(dP, 8);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) dq[dt] = MFMA32(lds_trfrag(kimg, C::DSTR, kk, dt * 32, lane), dsb[kk], dq[dt]);
+    if (kt + 1 < ntiles) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+  if (q < N) {
+    bf16* qrow = dqkv + ((size_t)b * N + q) * (3 * (size_t)D) + hd * dh;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * hh;
+        if (d < dh) {
+          bf16x4 a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = (bf16)dq[dt][4 * g4 + r];
+          *reinterpret_cast<bf16x4*>(qrow + d) = a;
+        }
+      }
+  }
+}
+
+// ======================================================================================================
+// launchers
+// ======================================================================================================
+template <int DP>
+static hipError_t fwd_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, float* lse, int B, int H, int N,
+                             int dh, hipStream_t s) {
+  using C = AttnCfg<DP>;
+  constexpr int smem = 2 * (64 * C::RSTR + 64 * C::TSTR);
+  const float scale = 1.0f / sqrtf((float)dh);
+  hipLaunchKernelGGL(attn_fwd_kernel<DP>, dim3((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse, H, N, dh,
+                     scale * 1.4426950408889634f, scale);
+  return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const bf16* out, const bf16* dout,
+                             const float* lse, bf16* dqkv, float* delta, int B, int H, int N, int dh, hipStream_t s) {
+  using C = AttnCfg<DP>;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const float c = scale * 1.4426950408889634f;
+  const size_t total = (size_t)B * N * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, H,
+                     N, dh);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  constexpr int smem_kv = 2 * (2 * 32 * C::DSTR + 2 * 32 * 4);
+  constexpr int smem_q = 2 * (32 * C::DSTR + 32 * C::RSTR);
+  dim3 grid((N + 127) / 128, B * H), block(256);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, lse, delta, dqkv, B, H, N, dh, c,
+                     scale);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, dout, lse, delta, dqkv, B, H, N, dh, c,
+                     scale);
+  return hipGetLastError();
+}
+
+static bool attn_shape_ok(int N, int dh, int DP, int H) {
+  if (dh % 8 || DP != ((dh + 15) / 16) * 16) return false;
+  if (DP != 16 && DP != 32 && DP != 48 && DP != 64 && DP != 80 && DP != 96) return false;
+  if ((size_t)N * DP * 2 >= (1ull << 31)) return false;
+  if ((size_t)N * H * dh * 2 >= (1ull << 31)) return false;
+  return true;
+}
+
+hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void* out, float* lse, int B, int H, int N,
+                    int dh, int DP, hipStream_t s) {
+  if (B * H == 0 || N == 0) return hipSuccess;
+  if (dtype == DT_F32)
+    return attn_ref_fwd((const float*)q, (const float*)k, (const float*)v, (float*)out, lse, B, H, N, dh, DP, s);
+  if (!attn_shape_ok(N, dh, DP, H)) return hipErrorInvalidValue;
+#define SGL_F(DPV) \
+  case DPV: return fwd_launch<DPV>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, B, H, N, dh, s);
+  switch (DP) {
+    SGL_F(16) SGL_F(32) SGL_F(48) SGL_F(64) SGL_F(80) SGL_F(96)
+  }
+#undef SGL_F
+  return hipErrorInvalidValue;
+}
+
+hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                    int dtype, void* dqkv, float* delta, float* /*unused*/, int B, int H, int N, int dh, int DP,
+                    hipStream_t s) {
+  if (B * H == 0 || N == 0) return hipSuccess;
+  if (dtype == DT_F32)
+    return attn_ref_bwd((const float*)q, (const float*)k, (const float*)v, (const float*)out, (const float*)dout, lse,
+                        (float*)dqkv, delta, B, H, N, dh, DP, s);
+  if (!attn_shape_ok(N, dh, DP, H)) return hipErrorInvalidValue;
+#define SGL_B(DPV)                                                                                             \
+  case DPV:                                                                                                    \
+    return bwd_launch<DPV>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)out, (const bf16*)dout, \
+                           lse, (bf16*)dqkv, delta, B, H, N, dh, s);
+  switch (DP) {
+    SGL_B(16) SGL_B(32) SGL_B(48) SGL_B(64) SGL_B(80) SGL_B(96)
+  }
+#undef SGL_B
+  return hipErrorInvalidValue;
+}
+
+size_t attn_bwd_scratch_bytes(int, int B, int H, int N, int, int) { return (size_t)B * H * N * sizeof(float); }
+
+}  // namespace sgl

@@ -1,0 +1,119 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) SigLIP-2 encoder kernels.
+// Wavefront = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgl {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define SGL_WAVE 64
+#define SGL_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- wave-64 reductions (DPP/shuffle; every lane ends with the result) ------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- typed element access --------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16> {
+  static __device__ __forceinline__ float ld(const bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16* p, float v) { *p = (bf16)v; }
+};
+
+// load / store NV (4 or 8) consecutive elements as float; pointers must be NV*sizeof(T)-aligned
+template <typename T, int NV> struct Vec;
+template <> struct Vec<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float* v) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Vec<float, 8> {
+  static __device__ __forceinline__ void ld(const float* p, float* v) {
+    Vec<float, 4>::ld(p, v); Vec<float, 4>::ld(p + 4, v + 4);
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) {
+    Vec<float, 4>::st(p, v); Vec<float, 4>::st(p + 4, v + 4);
+  }
+};
+template <> struct Vec<bf16, 4> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* v) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) {
+    bf16x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+};
+template <> struct Vec<bf16, 8> {
+  static __device__ __forceinline__ void ld(const bf16* p, float* v) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void st(bf16* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+// ---- GELU (tanh form, 'gelu_pytorch_tanh') and its derivative ---------------------------------------
+__device__ __forceinline__ float tanh_fast(float z) {
+  // tanh(z) = 1 - 2/(exp(2z)+1); saturates cleanly for |z| large
+  float e = __expf(2.0f * z);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float c = 0.7978845608028654f;
+  float t = tanh_fast(c * (x + 0.044715f * x * x * x));
+  return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float c = 0.7978845608028654f;
+  float x2 = x * x;
+  float t = tanh_fast(c * (x + 0.044715f * x * x2));
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x2);
+}
+
+// ---- buffer resources (hardware bounds check: out-of-range loads return 0, stores are dropped) -------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+#define SGL_OOB 0x80000000u  // any voffset >= num_records reads as zero
+
+}  // namespace sgl

@@ -1,0 +1,437 @@
+// HBM-bound helper kernels around the encoder GEMMs (gfx950): patch gather (im2col), weight-shadow casts,
+// bias-gradient column sums, position-table bicubic resize, and the 1-query attention-pool head.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sgl {
+
+// ---- im2col: Conv2d(3->D, k=s=P, 'valid') becomes a GEMM over K = 3*P*P (TF:modeling_siglip.py:124-130,178).
+// out[m][k], m = (b, gy, gx), k = c*P*P + ky*P + kx  (== weight.reshape(D,-1) order); k >= 3P² is zero pad.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, int channels_last,
+                                                     T* __restrict__ out, int B, int H, int W, int P, int gh, int gw,
+                                                     int Kp) {
+  const size_t total = (size_t)B * gh * gw * Kp;
+  const int K = 3 * P * P;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int k = (int)(idx % Kp);
+    const size_t m = idx / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int gx = (int)(m % gw);
+      const int gy = (int)((m / gw) % gh);
+      const int b = (int)(m / ((size_t)gw * gh));
+      const int c = k / (P * P);
+      const int r = k - c * P * P;
+      const int ky = r / P, kx = r - ky * P;
+      const int yy = gy * P + ky, xx = gx * P + kx;
+      const size_t src = channels_last ? (((size_t)b * H + yy) * W + xx) * 3 + c
+                                       : (((size_t)b * 3 + c) * H + yy) * W + xx;
+      v = pix[src];
+    }
+    Elem<T>::st(out + idx, v);
+  }
+}
+
+hipError_t im2col(const float* pix, int channels_last, void* out, int out_dtype, int B, int H, int W, int P, int Kp,
+                  hipStream_t s) {
+  const int gh = H / P, gw = W / P;
+  const size_t total = (size_t)B * gh * gw * Kp;
+  if (total == 0) return hipSuccess;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (out_dtype == DT_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, s, pix, channels_last, (bf16*)out, B, H, W, P,
+                       gh, gw, Kp);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, pix, channels_last, (float*)out, B, H, W,
+                       P, gh, gw, Kp);
+  return hipGetLastError();
+}
+
+// ---- weight shadows: dst[Rp][Cp] = pad(cast(src[R][C])) and the transposed form dst[Cp][Rp] ------------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int R, int C, int ld,
+                                                       T* __restrict__ dst, int Rp, int Cp, int ldd) {
+  const size_t total = (size_t)Rp * Cp;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c = (int)(idx % Cp);
+    const int r = (int)(idx / Cp);
+    const float v = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.f;
+    Elem<T>::st(dst + (size_t)r * ldd + c, v);
+  }
+}
+
+hipError_t cast_pad(const float* src, int R, int C, int ld, void* dst, int dst_dtype, int Rp, int Cp, int ldd,
+                    hipStream_t s) {
+  const size_t total = (size_t)Rp * Cp;
+  if (total == 0) return hipSuccess;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dst_dtype == DT_BF16)
+    hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(blocks), dim3(256), 0, s, src, R, C, ld, (bf16*)dst, Rp, Cp, ldd);
+  else
+    hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(blocks), dim3(256), 0, s, src, R, C, ld, (float*)dst, Rp, Cp, ldd);
+  return hipGetLastError();
+}
+
+// dst[c][r] = src[r][c]; dst is [Cp][Rp] zero padded.  32x32 LDS tile so both sides stay coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int R, int C, int ld,
+                                                             T* __restrict__ dst, int Cp, int Rp, int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    tile[ty + i * 8][tx] = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, r = r0 + tx;
+    if (c < Cp && r < Rp) Elem<T>::st(dst + (size_t)c * ldd + r, tile[tx][ty + i * 8]);
+  }
+}
+
+hipError_t cast_transpose_pad(const float* src, int R, int C, int ld, void* dst, int dst_dtype, int Cp, int Rp,
+                              int ldd, hipStream_t s) {
+  if ((size_t)Rp * Cp == 0) return hipSuccess;
+  dim3 grid((Cp + 31) / 32, (Rp + 31) / 32), block(256);
+  if (dst_dtype == DT_BF16)
+    hipLaunchKernelGGL(cast_transpose_kernel<bf16>, grid, block, 0, s, src, R, C, ld, (bf16*)dst, Cp, Rp, ldd);
+  else
+    hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, block, 0, s, src, R, C, ld, (float*)dst, Cp, Rp, ldd);
+  return hipGetLastError();
+}
+
+// ---- column sums (bias gradients): two deterministic stages ------------------------------------------
+int colsum_chunks(int M) {
+  int c = (M + 511) / 512;
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, int ld, int M, int N, int rows_per,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[8][257];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col0 = blockIdx.x * 256 + cg * 8;
+  const int r_begin = blockIdx.y * rows_per;
+  const int r_end = (r_begin + rows_per < M) ? r_begin + rows_per : M;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col0 < N) {
+    for (int r = r_begin + rl; r < r_end; r += 8) {
+      float v[8];
+      Vec<T, 8>::ld(in + (size_t)r * ld + col0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = acc[j];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][c];
+    partial[(size_t)blockIdx.y * N + blockIdx.x * 256 + c] = s;
+  }
+}
+
+hipError_t colsum(const void* in, int dtype, int ld, int M, int N, int n_out, float* partial, float* out,
+                  int accumulate, hipStream_t s) {
+  if (N % 8 || ld % 8) return hipErrorInvalidValue;
+  if (N == 0) return hipSuccess;
+  const int chunks = colsum_chunks(M);
+  const int rows_per = (M + chunks - 1) / chunks;
+  dim3 grid((N + 255) / 256, chunks), block(256);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)in, ld, M, N, rows_per, partial);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)in, ld, M, N, rows_per, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return reduce_partials(partial, chunks, N, out, n_out < N ? n_out : N, accumulate, s);
+}
+
+// out[j] (+)= sum_b in[b*n + j]   (d pos-table = sum over images of d embeddings)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ in, int B, size_t n,
+                                                        float* __restrict__ out, int accumulate) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += in[(size_t)b * n + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+hipError_t batch_sum(const float* in, int B, size_t n, float* out, int accumulate, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, B, n, out, accumulate);
+  return hipGetLastError();
+}
+
+// ---- position-table bicubic resize (F.interpolate bicubic, align_corners=False, A=-0.75;
+//      TF:modeling_siglip.py:137-173).  Runs once per resolution; tiny. ---------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+  const float A = -0.75f;
+  float x = t + 1.0f;
+  w[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+  x = t;
+  w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 1.0f - t;
+  w[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 2.0f - t;
+  w[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+__device__ __forceinline__ void cubic_taps(int o, int n_in, int n_out, int* idx, float* w) {
+  const float scale = (float)n_in / (float)n_out;
+  const float src = scale * ((float)o + 0.5f) - 0.5f;
+  const float fl = floorf(src);
+  cubic_coeffs(src - fl, w);
+  const int i0 = (int)fl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = i0 - 1 + k;
+    idx[k] = i < 0 ? 0 : (i > n_in - 1 ? n_in - 1 : i);
+  }
+}
+
+__global__ __launch_bounds__(256) void pos_resize_kernel(const float* __restrict__ table, int g0,
+                                                         float* __restrict__ out, int gh, int gw, int D) {
+  const size_t total = (size_t)gh * gw * D;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  const int o = (int)(idx / D);
+  const int oy = o / gw, ox = o - oy * gw;
+  int iy[4], ix[4];
+  float wy[4], wx[4];
+  cubic_taps(oy, g0, gh, iy, wy);
+  cubic_taps(ox, g0, gw, ix, wx);
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float rowv = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rowv += wx[b] * table[((size_t)iy[a] * g0 + ix[b]) * D + d];
+    acc += wy[a] * rowv;
+  }
+  out[idx] = acc;
+}
+hipError_t pos_resize(const float* table, int g0, float* out, int gh, int gw, int D, hipStream_t s) {
+  const size_t total = (size_t)gh * gw * D;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, g0, out, gh, gw,
+                     D);
+  return hipGetLastError();
+}
+
+// transpose of the above: dtable (+)= Wᵀ · dout.  16 fp32 atomics per output element; the table is tiny.
+__global__ __launch_bounds__(256) void pos_resize_bwd_kernel(const float* __restrict__ dout, int gh, int gw,
+                                                             float* __restrict__ dtable, int g0, int D) {
+  const size_t total = (size_t)gh * gw * D;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  const int o = (int)(idx / D);
+  const int oy = o / gw, ox = o - oy * gw;
+  int iy[4], ix[4];
+  float wy[4], wx[4];
+  cubic_taps(oy, g0, gh, iy, wy);
+  cubic_taps(ox, g0, gw, ix, wx);
+  const float g = dout[idx];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) atomicAdd(dtable + ((size_t)iy[a] * g0 + ix[b]) * D + d, g * wy[a] * wx[b]);
+}
+hipError_t pos_resize_bwd(const float* dout, int gh, int gw, float* dtable, int g0, int D, hipStream_t s) {
+  const size_t total = (size_t)gh * gw * D;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(pos_resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, gh, gw,
+                     dtable, g0, D);
+  return hipGetLastError();
+}
+
+// ---- small fp32 utilities ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, size_t n4, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+    if (b) v += reinterpret_cast<const f32x4*>(b)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) out[i] = a[i] + (b ? b[i] : 0.f);
+  }
+}
+hipError_t add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, n4, n);
+  return hipGetLastError();
+}
+hipError_t copy_f32(const float* src, float* dst, size_t n, hipStream_t s) { return add_f32(src, nullptr, dst, n, s); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ a, T* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    Elem<T>::st(out + i, a[i]);
+}
+hipError_t cast_f32(const float* src, void* dst, int dst_dtype, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dst_dtype == DT_BF16)
+    hipLaunchKernelGGL(cast_f32_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, src, (bf16*)dst, n);
+  else
+    hipLaunchKernelGGL(cast_f32_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, src, (float*)dst, n);
+  return hipGetLastError();
+}
+
+// ---- attention-pool head: one probe query per image (TF:modeling_siglip.py:633-637, nn.MultiheadAttention
+//      with q = probe, k = v = tokens).  One block per (b, h).  < 0.1 % of the FLOPs. ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_attn_fwd_kernel(const float* __restrict__ q, const T* __restrict__ K,
+                                                            const T* __restrict__ V, T* __restrict__ out,
+                                                            float* __restrict__ probs, int H, int N, int dh, int DP) {
+  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N] scores + [256] scratch + [dh] q
+  float* sc = pa_smem;
+  float* red = pa_smem + N;
+  float* qs = red + 256;
+  const int bh = blockIdx.x, h = bh % H, b = bh / H;
+  const T* Kb = K + (size_t)bh * N * DP;
+  const T* Vb = V + (size_t)bh * N * DP;
+  const float scale = rsqrtf((float)dh);
+  for (int d = threadIdx.x; d < dh; d += 256) qs[d] = q[h * dh + d];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s += qs[d] * Elem<T>::ld(Kb + (size_t)n * DP + d);
+    s *= scale;
+    sc[n] = s;
+    mx = fmaxf(mx, s);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float e = __expf(sc[n] - mx);
+    sc[n] = e;
+    sum += e;
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float inv = 1.0f / red[0];
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float p = sc[n] * inv;
+    sc[n] = p;
+    probs[(size_t)bh * N + n] = p;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dh; d += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += sc[n] * Elem<T>::ld(Vb + (size_t)n * DP + d);
+    Elem<T>::st(out + (size_t)b * H * dh + h * dh + d, acc);
+  }
+}
+
+hipError_t pool_attn_fwd(const float* q, const void* K, const void* V, int dtype, void* out, float* probs, int B,
+                         int H, int N, int dh, int DP, hipStream_t s) {
+  if (B * H == 0) return hipSuccess;
+  const size_t smem = (size_t)(N + 256 + dh) * sizeof(float);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pool_attn_fwd_kernel<bf16>, dim3(B * H), dim3(256), smem, s, q, (const bf16*)K, (const bf16*)V,
+                       (bf16*)out, probs, H, N, dh, DP);
+  else
+    hipLaunchKernelGGL(pool_attn_fwd_kernel<float>, dim3(B * H), dim3(256), smem, s, q, (const float*)K,
+                       (const float*)V, (float*)out, probs, H, N, dh, DP);
+  return hipGetLastError();
+}
+
+// backward: dV[n,d] = p_n * do[d];  dp_n = do·V[n];  ds_n = p_n (dp_n - Σ p dp) * scale;
+//           dK[n,d] = ds_n q[d];   dq[d] (per image) = Σ_n ds_n K[n,d]
+// dkv is token-major [B*N][2*H*dh] (k block then v block) — the A operand of the kv-projection backward GEMMs.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ K,
+                                                            const T* __restrict__ V, const float* __restrict__ probs,
+                                                            const float* __restrict__ dout, T* __restrict__ dkv,
+                                                            float* __restrict__ dq_partial, int H, int N, int dh,
+                                                            int DP) {
+  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N] ds + [256] red + [dh] q + [dh] do
+  float* ds = pa_smem;
+  float* red = pa_smem + N;
+  float* qs = red + 256;
+  float* dos = qs + dh;
+  const int bh = blockIdx.x, h = bh % H, b = bh / H;
+  const int D = H * dh;
+  const T* Kb = K + (size_t)bh * N * DP;
+  const T* Vb = V + (size_t)bh * N * DP;
+  const float scale = rsqrtf((float)dh);
+  for (int d = threadIdx.x; d < dh; d += 256) {
+    qs[d] = q[h * dh + d];
+    dos[d] = dout[(size_t)b * D + h * dh + d];
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float dp = 0.f;
+    for (int d = 0; d < dh; ++d) dp += dos[d] * Elem<T>::ld(Vb + (size_t)n * DP + d);
+    ds[n] = dp;
+    part += probs[(size_t)bh * N + n] * dp;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float dot = red[0];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float p = probs[(size_t)bh * N + n];
+    const float g = p * (ds[n] - dot) * scale;
+    ds[n] = g;
+    T* row = dkv + ((size_t)b * N + n) * (2 * D);
+    for (int d = 0; d < dh; ++d) {
+      Elem<T>::st(row + h * dh + d, g * qs[d]);
+      Elem<T>::st(row + D + h * dh + d, p * dos[d]);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dh; d += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += ds[n] * Elem<T>::ld(Kb + (size_t)n * DP + d);
+    dq_partial[(size_t)b * D + h * dh + d] = acc;
+  }
+}
+
+hipError_t pool_attn_bwd(const float* q, const void* K, const void* V, int dtype, const float* probs,
+                         const float* dout, void* dkv, float* dq_partial, int B, int H, int N, int dh, int DP,
+                         hipStream_t s) {
+  if (B * H == 0) return hipSuccess;
+  const size_t smem = (size_t)(N + 256 + 2 * dh) * sizeof(float);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(pool_attn_bwd_kernel<bf16>, dim3(B * H), dim3(256), smem, s, q, (const bf16*)K, (const bf16*)V,
+                       probs, dout, (bf16*)dkv, dq_partial, H, N, dh, DP);
+  else
+    hipLaunchKernelGGL(pool_attn_bwd_kernel<float>, dim3(B * H), dim3(256), smem, s, q, (const float*)K,
+                       (const float*)V, probs, dout, (float*)dkv, dq_partial, H, N, dh, DP);
+  return hipGetLastError();
+}
+
+}  // namespace sgl

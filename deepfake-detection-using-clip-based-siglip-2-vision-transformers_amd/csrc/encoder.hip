@@ -1,0 +1,853 @@
+// Host side of libsiglip_hip.so: the C ABI of include/siglip_hip.h.  Orchestrates the hand-written gfx950
+// kernels into the SigLIP-2 vision encoder forward / backward:
+//   embeddings   TF:models/siglip/modeling_siglip.py:175-185      (im2col + GEMM, bias + position fused)
+//   27x block    TF:...:335-356   x += out_proj(attn(qkv(LN1 x)));  x += fc2(gelu_tanh(fc1(LN2 x)))
+//   post LN      TF:...:612        pooling head  TF:...:633-643
+// The residual stream, LayerNorm statistics and softmax run in fp32 in both compute modes; GEMM / attention
+// operands are bf16 (MFMA) or fp32 (strict).  The ctx owns no device memory: every buffer is the caller's.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+#include "siglip_hip.h"
+
+using namespace sgl;
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += align256(bytes);
+    return o;
+  }
+};
+
+struct ShadowLayer {
+  size_t wqkv, wqkv_t, wo, wo_t, w1, w1_t, w2, w2_t, bqkv, b1;
+};
+
+}  // namespace
+
+struct sgl_ctx {
+  sgl_config cfg;
+  int D, I, Ip, L, H, dh, DP, P, K0, Kp, g0, dt;
+  size_t es;  // element size of the compute dtype
+  int last_hip = 0;
+  // shadow arena layout (config-only)
+  size_t sh_wpatch = 0;
+  std::vector<ShadowLayer> sh_layers;
+  size_t sh_hwkv = 0, sh_hwkv_t = 0, sh_hwo = 0, sh_hwo_t = 0, sh_hw1 = 0, sh_hw1_t = 0, sh_hw2 = 0, sh_hw2_t = 0,
+         sh_hb1 = 0;
+  size_t sh_total = 0;
+};
+
+namespace {
+
+// Per-call activation / workspace layout (pure function of ctx, B, grid, train).
+struct Layout {
+  int B, gh, gw, N, M;
+  bool train;
+  // activation region ("saved" when training, a slice of ws otherwise)
+  size_t a_im2col, a_pos;
+  size_t a_layer0, a_layer_stride;
+  size_t r_stats1, r_h1, r_qkv, r_attn, r_lse, r_xmid, r_stats2, r_h2, r_u, r_a;  // relative to a layer base
+  size_t a_pstats, a_lastlp, a_kvh, a_qp, a_probs, a_ao, a_h0, a_hstats, a_hl, a_hu, a_ha;
+  size_t act_total;
+  // backward scratch (ws)
+  size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_lnpart, w_cspart, w_dlast;
+  size_t w_hg, w_hdu, w_hdh, w_hdao, w_hdqpart, w_hdqp, w_hdh0;
+  size_t ws_bwd_total;
+  size_t saved_total, ws_total, ws_act_off;
+
+  Layout(const sgl_ctx* c, int B_, int Himg, int Wimg, bool train_) {
+    B = B_;
+    train = train_;
+    gh = Himg / c->P;
+    gw = Wimg / c->P;
+    N = gh * gw;
+    M = B * N;
+    const size_t es = c->es, D = c->D, Ip = c->Ip, Mz = (size_t)M;
+    Bump a;
+    a_im2col = a.take(Mz * c->Kp * es);
+    a_pos = a.take((size_t)N * D * 4);
+    Bump r;
+    r_stats1 = r.take(Mz * 2 * 4);
+    r_h1 = r.take(Mz * D * es);
+    r_qkv = r.take((size_t)3 * B * c->H * N * c->DP * es);
+    r_attn = r.take(Mz * D * es);
+    r_lse = r.take((size_t)B * c->H * N * 4);
+    r_xmid = r.take(Mz * D * 4);
+    r_stats2 = r.take(Mz * 2 * 4);
+    r_h2 = r.take(Mz * D * es);
+    r_u = r.take(Mz * Ip * es);
+    r_a = r.take(Mz * Ip * es);
+    a_layer_stride = train ? r.off : 0;
+    a_layer0 = a.take(train ? r.off * (size_t)c->L : r.off);
+    a_pstats = a.take(Mz * 2 * 4);
+    a_lastlp = a.take(Mz * D * es);
+    a_kvh = a.take((size_t)2 * B * c->H * N * c->DP * es);
+    a_qp = a.take(D * 4);
+    a_probs = a.take((size_t)B * c->H * N * 4);
+    a_ao = a.take((size_t)B * D * es);
+    a_h0 = a.take((size_t)B * D * 4);
+    a_hstats = a.take((size_t)B * 2 * 4);
+    a_hl = a.take((size_t)B * D * es);
+    a_hu = a.take((size_t)B * Ip * es);
+    a_ha = a.take((size_t)B * Ip * es);
+    act_total = a.off;
+
+    Bump w;
+    if (train) {
+      const size_t widest = (size_t)(Ip > 3 * D ? Ip : 3 * D);
+      w_dx = w.take(Mz * D * 4);
+      w_g = w.take(Mz * D * es);
+      w_du = w.take(Mz * Ip * es);
+      w_dh = w.take(Mz * D * es);
+      w_dqkv = w.take(Mz * 3 * D * es);
+      w_delta = w.take((size_t)B * c->H * N * 4);
+      w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 2 * D * 4);
+      w_cspart = w.take((size_t)colsum_chunks(M) * widest * 4);
+      w_dlast = w.take(Mz * D * 4);
+      w_hg = w.take((size_t)B * D * es);
+      w_hdu = w.take((size_t)B * Ip * es);
+      w_hdh = w.take((size_t)B * D * es);
+      w_hdao = w.take((size_t)B * D * 4);
+      w_hdqpart = w.take((size_t)B * D * 4);
+      w_hdqp = w.take(D * 4);
+      w_hdh0 = w.take((size_t)B * D * 4);
+    } else {
+      w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_lnpart = w_cspart = w_dlast = 0;
+      w_hg = w_hdu = w_hdh = w_hdao = w_hdqpart = w_hdqp = w_hdh0 = 0;
+    }
+    ws_bwd_total = w.off;
+    if (train) {
+      saved_total = act_total;
+      ws_act_off = 0;
+      ws_total = ws_bwd_total;
+    } else {
+      saved_total = 0;
+      ws_act_off = ws_bwd_total;
+      ws_total = ws_bwd_total + act_total;
+    }
+    if (ws_total == 0) ws_total = 256;
+  }
+  size_t layer_base(int l) const { return a_layer0 + a_layer_stride * (size_t)l; }
+};
+
+#define CK(expr)                        \
+  do {                                  \
+    hipError_t e_ = (expr);             \
+    if (e_ != hipSuccess) {             \
+      ctx->last_hip = (int)e_;          \
+      return SGL_ERR_HIP;               \
+    }                                   \
+  } while (0)
+
+inline char* at(void* base, size_t off) { return reinterpret_cast<char*>(base) + off; }
+inline const char* at(const void* base, size_t off) { return reinterpret_cast<const char*>(base) + off; }
+
+hipError_t gemm_nt(const sgl_ctx* c, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
+                   int out_dt, const EpiParams& p, hipStream_t s) {
+  if (c->dt == DT_BF16) return gemm_nt_bf16(A, lda, B, ldb, M, N, K, epi, out_dt, p, s);
+  return gemm_f32_generic((const float*)A, lda, 1, (const float*)B, ldb, 1, M, N, K, epi, out_dt, p, s);
+}
+
+// dW[N1,N2] (+)= A[:, :N1]^T · B[:, :N2]   (reduction over the Mred rows)
+hipError_t gemm_tn(const sgl_ctx* c, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2,
+                   float* out, int ldo, int accumulate, hipStream_t s) {
+  EpiParams p;
+  p.out = out;
+  p.ldo = ldo;
+  p.accumulate = accumulate;
+  if (c->dt == DT_BF16) {
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    int splits = (512 + tiles - 1) / tiles;
+    const int max_splits = Mred / 512 > 0 ? Mred / 512 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+    return gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, s);
+  }
+  return gemm_f32_generic((const float*)A, 1, lda, (const float*)B, 1, ldb, N1, N2, Mred, EPI_F32, DT_F32, p, s);
+}
+
+bool shape_ok(const sgl_ctx* c, int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return false;
+  if (H < c->P || W < c->P) return false;  // 'valid' conv: trailing pixels beyond gh*P are ignored
+  const long N = (long)(H / c->P) * (W / c->P);
+  if ((long)B * N > (1l << 24)) return false;
+  return true;
+}
+
+}  // namespace
+
+// =======================================================================================================
+extern "C" {
+
+int sgl_abi_version(void) { return 1; }
+
+const char* sgl_status_string(int status) {
+  switch (status) {
+    case SGL_OK: return "ok";
+    case SGL_ERR_BAD_SHAPE: return "bad shape";
+    case SGL_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SGL_ERR_WORKSPACE: return "buffer too small";
+    case SGL_ERR_HIP: return "HIP error";
+    case SGL_ERR_NULL: return "null pointer";
+  }
+  return "unknown";
+}
+
+sgl_ctx* sgl_create(const sgl_config* cfg) {
+  if (!cfg) return nullptr;
+  if (cfg->hidden_size <= 0 || cfg->num_heads <= 0 || cfg->hidden_size % cfg->num_heads) return nullptr;
+  const int dh = cfg->hidden_size / cfg->num_heads;
+  if (dh % 8 || dh > 96 || cfg->hidden_size % 8 || cfg->hidden_size > 2048) return nullptr;
+  if (cfg->intermediate_size <= 0 || cfg->num_layers < 0 || cfg->patch_size <= 0 || cfg->native_grid <= 0)
+    return nullptr;
+  if (cfg->compute_dtype != SGL_DTYPE_F32 && cfg->compute_dtype != SGL_DTYPE_BF16) return nullptr;
+  sgl_ctx* c = new (std::nothrow) sgl_ctx();
+  if (!c) return nullptr;
+  c->cfg = *cfg;
+  c->D = cfg->hidden_size;
+  c->I = cfg->intermediate_size;
+  c->Ip = round_up(cfg->intermediate_size, 128);
+  c->L = cfg->num_layers;
+  c->H = cfg->num_heads;
+  c->dh = dh;
+  c->DP = round_up(dh, 16);
+  c->P = cfg->patch_size;
+  c->K0 = 3 * c->P * c->P;
+  c->Kp = round_up(c->K0, 64);
+  c->g0 = cfg->native_grid;
+  c->dt = cfg->compute_dtype;
+  c->es = dtype_size(c->dt);
+  const size_t es = c->es, D = c->D, Ip = c->Ip;
+  Bump b;
+  c->sh_wpatch = b.take(D * c->Kp * es);
+  c->sh_layers.resize(c->L);
+  for (int l = 0; l < c->L; ++l) {
+    ShadowLayer& s = c->sh_layers[l];
+    s.wqkv = b.take(3 * D * D * es);
+    s.wqkv_t = b.take(3 * D * D * es);
+    s.wo = b.take(D * D * es);
+    s.wo_t = b.take(D * D * es);
+    s.w1 = b.take(Ip * D * es);
+    s.w1_t = b.take(Ip * D * es);
+    s.w2 = b.take(Ip * D * es);
+    s.w2_t = b.take(Ip * D * es);
+    s.bqkv = b.take(3 * D * 4);
+    s.b1 = b.take(Ip * 4);
+  }
+  if (cfg->use_head) {
+    c->sh_hwkv = b.take(2 * D * D * es);
+    c->sh_hwkv_t = b.take(2 * D * D * es);
+    c->sh_hwo = b.take(D * D * es);
+    c->sh_hwo_t = b.take(D * D * es);
+    c->sh_hw1 = b.take(Ip * D * es);
+    c->sh_hw1_t = b.take(Ip * D * es);
+    c->sh_hw2 = b.take(Ip * D * es);
+    c->sh_hw2_t = b.take(Ip * D * es);
+    c->sh_hb1 = b.take(Ip * 4);
+  }
+  c->sh_total = b.off;
+  return c;
+}
+
+void sgl_destroy(sgl_ctx* ctx) { delete ctx; }
+
+int sgl_last_hip_error(const sgl_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int sgl_query_sizes(const sgl_ctx* ctx, int B, int H, int W, int train, size_t* shadow_bytes, size_t* saved_bytes,
+                    size_t* ws_bytes) {
+  if (!ctx) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  Layout lay(ctx, B, H, W, train != 0);
+  if (shadow_bytes) *shadow_bytes = ctx->sh_total;
+  if (saved_bytes) *saved_bytes = lay.saved_total;
+  if (ws_bytes) *ws_bytes = lay.ws_total;
+  return SGL_OK;
+}
+
+int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes, sgl_stream stream) {
+  if (!ctx || !w || !shadow || (ctx->L > 0 && !w->layers)) return SGL_ERR_NULL;
+  if (shadow_bytes < ctx->sh_total) return SGL_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, dt = ctx->dt;
+  CK(cast_pad(w->patch_w, D, ctx->K0, ctx->K0, at(shadow, ctx->sh_wpatch), dt, D, ctx->Kp, ctx->Kp, s));
+  for (int l = 0; l < ctx->L; ++l) {
+    const sgl_layer_weights& lw = w->layers[l];
+    const ShadowLayer& sl = ctx->sh_layers[l];
+    const float* qkv_w[3] = {lw.q_w, lw.k_w, lw.v_w};
+    const float* qkv_b[3] = {lw.q_b, lw.k_b, lw.v_b};
+    for (int j = 0; j < 3; ++j) {
+      CK(cast_pad(qkv_w[j], D, D, D, at(shadow, sl.wqkv + (size_t)j * D * D * ctx->es), dt, D, D, D, s));
+      CK(cast_transpose_pad(qkv_w[j], D, D, D, at(shadow, sl.wqkv_t + (size_t)j * D * ctx->es), dt, D, D, 3 * D, s));
+      CK(copy_f32(qkv_b[j], reinterpret_cast<float*>(at(shadow, sl.bqkv)) + (size_t)j * D, D, s));
+    }
+    CK(cast_pad(lw.o_w, D, D, D, at(shadow, sl.wo), dt, D, D, D, s));
+    CK(cast_transpose_pad(lw.o_w, D, D, D, at(shadow, sl.wo_t), dt, D, D, D, s));
+    CK(cast_pad(lw.fc1_w, I, D, D, at(shadow, sl.w1), dt, Ip, D, D, s));
+    CK(cast_transpose_pad(lw.fc1_w, I, D, D, at(shadow, sl.w1_t), dt, D, Ip, Ip, s));
+    CK(cast_pad(lw.fc2_w, D, I, I, at(shadow, sl.w2), dt, D, Ip, Ip, s));
+    CK(cast_transpose_pad(lw.fc2_w, D, I, I, at(shadow, sl.w2_t), dt, Ip, D, D, s));
+    CK(cast_pad(lw.fc1_b, 1, I, I, at(shadow, sl.b1), DT_F32, 1, Ip, Ip, s));
+  }
+  if (ctx->cfg.use_head) {
+    const float* kv_w = w->in_proj_w + (size_t)D * D;
+    CK(cast_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv), dt, 2 * D, D, D, s));
+    CK(cast_transpose_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv_t), dt, D, 2 * D, 2 * D, s));
+    CK(cast_pad(w->out_proj_w, D, D, D, at(shadow, ctx->sh_hwo), dt, D, D, D, s));
+    CK(cast_transpose_pad(w->out_proj_w, D, D, D, at(shadow, ctx->sh_hwo_t), dt, D, D, D, s));
+    CK(cast_pad(w->head_fc1_w, I, D, D, at(shadow, ctx->sh_hw1), dt, Ip, D, D, s));
+    CK(cast_transpose_pad(w->head_fc1_w, I, D, D, at(shadow, ctx->sh_hw1_t), dt, D, Ip, Ip, s));
+    CK(cast_pad(w->head_fc2_w, D, I, I, at(shadow, ctx->sh_hw2), dt, D, Ip, Ip, s));
+    CK(cast_transpose_pad(w->head_fc2_w, D, I, I, at(shadow, ctx->sh_hw2_t), dt, Ip, D, D, s));
+    CK(cast_pad(w->head_fc1_b, 1, I, I, at(shadow, ctx->sh_hb1), DT_F32, 1, Ip, Ip, s));
+  }
+  return SGL_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------
+int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
+                int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
+                float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  if (!ctx || !w || !shadow || !pixels || !hidden_states || !last_hidden) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  const bool train = saved != nullptr;
+  Layout lay(ctx, B, H, W, train);
+  if (train && saved_bytes < lay.saved_total) return SGL_ERR_WORKSPACE;
+  // training forward keeps everything in `saved`; the workspace is only touched by inference and backward
+  if (!train && (!ws || ws_bytes < lay.ws_total)) return SGL_ERR_WORKSPACE;
+  if (hs_slots < 2 || (train && hs_slots < ctx->L + 1)) return SGL_ERR_BAD_SHAPE;
+  if (!(lay.gh == ctx->g0 && lay.gw == ctx->g0) && !interpolate_pos) return SGL_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = ctx->D, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh, DP = ctx->DP;
+  char* act = train ? reinterpret_cast<char*>(saved) : at(ws, lay.ws_act_off);
+  const size_t hs_stride = (size_t)M * D;
+  auto hs = [&](int l) { return hidden_states + (size_t)(l % hs_slots) * hs_stride; };
+
+  // ---- embeddings
+  CK(im2col(pixels, channels_last, act + lay.a_im2col, dt, B, H, W, ctx->P, ctx->Kp, s));
+  const float* pos = w->pos;
+  if (!(lay.gh == ctx->g0 && lay.gw == ctx->g0)) {
+    float* pr = reinterpret_cast<float*>(act + lay.a_pos);
+    CK(pos_resize(w->pos, ctx->g0, pr, lay.gh, lay.gw, D, s));
+    pos = pr;
+  }
+  {
+    EpiParams p;
+    p.out = hs(0);
+    p.ldo = D;
+    p.bias = w->patch_b;
+    p.pos = pos;
+    p.pos_rows = N;
+    CK(gemm_nt(ctx, act + lay.a_im2col, ctx->Kp, at(shadow, ctx->sh_wpatch), ctx->Kp, M, D, ctx->Kp, EPI_POS_F32,
+               DT_F32, p, s));
+  }
+  // ---- blocks
+  for (int l = 0; l < ctx->L; ++l) {
+    const sgl_layer_weights& lw = w->layers[l];
+    const ShadowLayer& sl = ctx->sh_layers[l];
+    char* lb = act + lay.layer_base(l);
+    float* x = hs(l);
+    float* xo = hs(l + 1);
+    float* st1 = reinterpret_cast<float*>(lb + lay.r_stats1);
+    float* st2 = reinterpret_cast<float*>(lb + lay.r_stats2);
+    float* xmid = reinterpret_cast<float*>(lb + lay.r_xmid);
+    CK(layernorm_fwd(x, lw.ln1_w, lw.ln1_b, lb + lay.r_h1, dt, D, st1, st1 + M, M, D, ctx->cfg.layer_norm_eps, s));
+    {
+      EpiParams p;
+      p.out = lb + lay.r_qkv;
+      p.bias = reinterpret_cast<const float*>(at(shadow, sl.bqkv));
+      p.tokens = N;
+      p.heads = Hh;
+      p.head_dim = dh;
+      p.head_dim_pad = DP;
+      p.batch = B;
+      CK(gemm_nt(ctx, lb + lay.r_h1, D, at(shadow, sl.wqkv), D, M, 3 * D, D, EPI_QKV, dt, p, s));
+    }
+    {
+      const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
+      char* q = lb + lay.r_qkv;
+      CK(attn_fwd(q, q + hsz, q + 2 * hsz, dt, lb + lay.r_attn, reinterpret_cast<float*>(lb + lay.r_lse), B, Hh, N, dh,
+                  DP, s));
+    }
+    {
+      EpiParams p;
+      p.out = xmid;
+      p.ldo = D;
+      p.bias = lw.o_b;
+      p.res = x;
+      p.ldr = D;
+      CK(gemm_nt(ctx, lb + lay.r_attn, D, at(shadow, sl.wo), D, M, D, D, EPI_RES_F32, DT_F32, p, s));
+    }
+    CK(layernorm_fwd(xmid, lw.ln2_w, lw.ln2_b, lb + lay.r_h2, dt, D, st2, st2 + M, M, D, ctx->cfg.layer_norm_eps, s));
+    {
+      EpiParams p;
+      p.out = lb + lay.r_u;
+      p.ldo = Ip;
+      p.out2 = lb + lay.r_a;
+      p.ldo2 = Ip;
+      p.bias = reinterpret_cast<const float*>(at(shadow, sl.b1));
+      CK(gemm_nt(ctx, lb + lay.r_h2, D, at(shadow, sl.w1), D, M, Ip, D, EPI_BIAS_GELU, dt, p, s));
+    }
+    {
+      EpiParams p;
+      p.out = xo;
+      p.ldo = D;
+      p.bias = lw.fc2_b;
+      p.res = xmid;
+      p.ldr = D;
+      CK(gemm_nt(ctx, lb + lay.r_a, Ip, at(shadow, sl.w2), Ip, M, D, Ip, EPI_RES_F32, DT_F32, p, s));
+    }
+  }
+  // ---- post layernorm + attention-pool head
+  float* pst = reinterpret_cast<float*>(act + lay.a_pstats);
+  CK(layernorm_fwd(hs(ctx->L), w->post_ln_w, w->post_ln_b, last_hidden, DT_F32, D, pst, pst + M, M, D,
+                   ctx->cfg.layer_norm_eps, s));
+  if (ctx->cfg.use_head && pooled) {
+    CK(cast_f32(last_hidden, act + lay.a_lastlp, dt, (size_t)M * D, s));
+    {
+      EpiParams p;
+      p.out = act + lay.a_kvh;
+      p.bias = w->in_proj_b + D;
+      p.tokens = N;
+      p.heads = Hh;
+      p.head_dim = dh;
+      p.head_dim_pad = DP;
+      p.batch = B;
+      CK(gemm_nt(ctx, act + lay.a_lastlp, D, at(shadow, ctx->sh_hwkv), D, M, 2 * D, D, EPI_QKV, dt, p, s));
+    }
+    float* qp = reinterpret_cast<float*>(act + lay.a_qp);
+    {
+      EpiParams p;
+      p.out = qp;
+      p.ldo = D;
+      p.bias = w->in_proj_b;
+      CK(gemm_f32_generic(w->probe, D, 1, w->in_proj_w, D, 1, 1, D, D, EPI_F32, DT_F32, p, s));
+    }
+    const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
+    CK(pool_attn_fwd(qp, act + lay.a_kvh, act + lay.a_kvh + hsz, dt, act + lay.a_ao,
+                     reinterpret_cast<float*>(act + lay.a_probs), B, Hh, N, dh, DP, s));
+    float* h0 = reinterpret_cast<float*>(act + lay.a_h0);
+    {
+      EpiParams p;
+      p.out = h0;
+      p.ldo = D;
+      p.bias = w->out_proj_b;
+      CK(gemm_nt(ctx, act + lay.a_ao, D, at(shadow, ctx->sh_hwo), D, B, D, D, EPI_F32, DT_F32, p, s));
+    }
+    float* hst = reinterpret_cast<float*>(act + lay.a_hstats);
+    CK(layernorm_fwd(h0, w->head_ln_w, w->head_ln_b, act + lay.a_hl, dt, D, hst, hst + B, B, D,
+                     ctx->cfg.layer_norm_eps, s));
+    {
+      EpiParams p;
+      p.out = act + lay.a_hu;
+      p.ldo = Ip;
+      p.out2 = act + lay.a_ha;
+      p.ldo2 = Ip;
+      p.bias = reinterpret_cast<const float*>(at(shadow, ctx->sh_hb1));
+      CK(gemm_nt(ctx, act + lay.a_hl, D, at(shadow, ctx->sh_hw1), D, B, Ip, D, EPI_BIAS_GELU, dt, p, s));
+    }
+    {
+      EpiParams p;
+      p.out = pooled;
+      p.ldo = D;
+      p.bias = w->head_fc2_b;
+      p.res = h0;
+      p.ldr = D;
+      CK(gemm_nt(ctx, act + lay.a_ha, Ip, at(shadow, ctx->sh_hw2), Ip, B, D, Ip, EPI_RES_F32, DT_F32, p, s));
+    }
+  }
+  return SGL_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// backward
+// -------------------------------------------------------------------------------------------------------
+namespace {
+
+// bias gradient helper: out[0:n_out] (+)= colsum(in[:, 0:N])
+int bias_grad(sgl_ctx* ctx, const Layout& lay, void* ws, const void* in, int ld, int M, int N, int n_out, float* out,
+              int accumulate, hipStream_t s) {
+  if (!out) return SGL_OK;
+  CK(colsum(in, ctx->dt, ld, M, N, n_out, reinterpret_cast<float*>(at(ws, lay.w_cspart)), out, accumulate, s));
+  return SGL_OK;
+}
+
+// LayerNorm backward + dgamma/dbeta reduction
+int ln_backward(sgl_ctx* ctx, const Layout& lay, void* ws, const void* dy, int dy_dt, const float* x, const float* stats,
+                int rows, const float* gamma, const float* dres, float* dx, void* dx_lp, float* dgamma, float* dbeta,
+                int accumulate, hipStream_t s) {
+  const int D = ctx->D;
+  const bool want = dgamma || dbeta;
+  const int nblk = layernorm_bwd_blocks(rows);
+  float* part = reinterpret_cast<float*>(at(ws, lay.w_lnpart));
+  CK(layernorm_bwd(dy, dy_dt, D, x, stats, stats + rows, gamma, dres, dx, dx_lp, ctx->dt, want ? part : nullptr, nblk,
+                   rows, D, s));
+  if (dgamma) CK(reduce_partials(part, nblk, 2 * D, dgamma, D, accumulate, s));
+  if (dbeta) CK(reduce_partials(part + D, nblk, 2 * D, dbeta, D, accumulate, s));
+  return SGL_OK;
+}
+
+#define RET(expr)                 \
+  do {                            \
+    int r_ = (expr);              \
+    if (r_ != SGL_OK) return r_;  \
+  } while (0)
+
+int check_bwd_args(const sgl_ctx* ctx, const Layout& lay, const void* saved, size_t saved_bytes, void* ws,
+                   size_t ws_bytes) {
+  if (!saved || !ws) return SGL_ERR_NULL;
+  if (saved_bytes < lay.saved_total || ws_bytes < lay.ws_total) return SGL_ERR_WORKSPACE;
+  return SGL_OK;
+}
+
+}  // namespace
+
+int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                       const float* hidden_states, const float* d_last_hidden, const float* d_pooled,
+                       const float* d_tap_last, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                       sgl_stream stream) {
+  if (!ctx || !w || !shadow || !g || !hidden_states) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  Layout lay(ctx, B, H, W, true);
+  RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh,
+            DP = ctx->DP;
+  const int acc = g->accumulate;
+  const char* act = reinterpret_cast<const char*>(saved);
+  float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
+  void* gbuf = at(ws, lay.w_g);
+  const float* hsL = hidden_states + (size_t)ctx->L * M * D;
+  const float* dlast = d_last_hidden;  // gradient w.r.t. post_layernorm output
+
+  if (ctx->cfg.use_head && d_pooled) {
+    float* dlast_buf = reinterpret_cast<float*>(at(ws, lay.w_dlast));
+    const float* h0 = reinterpret_cast<const float*>(act + lay.a_h0);
+    const float* hst = reinterpret_cast<const float*>(act + lay.a_hstats);
+    const float* qp = reinterpret_cast<const float*>(act + lay.a_qp);
+    void* hg = at(ws, lay.w_hg);
+    void* hdu = at(ws, lay.w_hdu);
+    void* hdh = at(ws, lay.w_hdh);
+    float* hdao = reinterpret_cast<float*>(at(ws, lay.w_hdao));
+    float* hdh0 = reinterpret_cast<float*>(at(ws, lay.w_hdh0));
+    // pooled = h0 + fc2(gelu(fc1(LN(h0))))
+    CK(cast_f32(d_pooled, hg, dt, (size_t)B * D, s));
+    {
+      EpiParams p;
+      p.out = hdu;
+      p.ldo = Ip;
+      p.aux = act + lay.a_hu;
+      p.ldaux = Ip;
+      CK(gemm_nt(ctx, hg, D, at(shadow, ctx->sh_hw2_t), D, B, Ip, D, EPI_GELU_BWD, dt, p, s));
+    }
+    if (g->head_fc2_w) CK(gemm_tn(ctx, hg, D, act + lay.a_ha, Ip, B, D, I, g->head_fc2_w, I, acc, s));
+    RET(bias_grad(ctx, lay, ws, hg, D, B, D, D, g->head_fc2_b, acc, s));
+    {
+      EpiParams p;
+      p.out = hdh;
+      p.ldo = D;
+      CK(gemm_nt(ctx, hdu, Ip, at(shadow, ctx->sh_hw1_t), Ip, B, D, Ip, EPI_STORE, dt, p, s));
+    }
+    if (g->head_fc1_w) CK(gemm_tn(ctx, hdu, Ip, act + lay.a_hl, D, B, I, D, g->head_fc1_w, D, acc, s));
+    RET(bias_grad(ctx, lay, ws, hdu, Ip, B, Ip, I, g->head_fc1_b, acc, s));
+    // LN backward (+ residual d_pooled): dh0, low-precision copy into hg
+    RET(ln_backward(ctx, lay, ws, hdh, dt, h0, hst, B, w->head_ln_w, d_pooled, hdh0, hg, g->head_ln_w, g->head_ln_b,
+                    acc, s));
+    // h0 = ao · Woᵀ + bo
+    {
+      EpiParams p;
+      p.out = hdao;
+      p.ldo = D;
+      CK(gemm_nt(ctx, hg, D, at(shadow, ctx->sh_hwo_t), D, B, D, D, EPI_F32, DT_F32, p, s));
+    }
+    if (g->out_proj_w) CK(gemm_tn(ctx, hg, D, act + lay.a_ao, D, B, D, D, g->out_proj_w, D, acc, s));
+    RET(bias_grad(ctx, lay, ws, hg, D, B, D, D, g->out_proj_b, acc, s));
+    // attention pool backward
+    const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
+    void* dkv = at(ws, lay.w_dqkv);  // [M][2D]
+    float* dqpart = reinterpret_cast<float*>(at(ws, lay.w_hdqpart));
+    float* dqp = reinterpret_cast<float*>(at(ws, lay.w_hdqp));
+    CK(pool_attn_bwd(qp, act + lay.a_kvh, act + lay.a_kvh + hsz, dt,
+                     reinterpret_cast<const float*>(act + lay.a_probs), hdao, dkv, dqpart, B, Hh, N, dh, DP, s));
+    if (g->probe || g->in_proj_w || g->in_proj_b) {
+      CK(batch_sum(dqpart, B, (size_t)D, dqp, 0, s));
+      if (g->in_proj_w) {  // d Wq[i,j] = dqp[i] * probe[j]
+        EpiParams p;
+        p.out = g->in_proj_w;
+        p.ldo = D;
+        p.accumulate = acc;
+        CK(gemm_f32_generic(dqp, 1, 1, w->probe, 1, 1, D, D, 1, EPI_F32, DT_F32, p, s));
+      }
+      if (g->in_proj_b) CK(batch_sum(dqp, 1, (size_t)D, g->in_proj_b, acc, s));
+      if (g->probe) {  // dprobe[j] = sum_i dqp[i] Wq[i,j]
+        EpiParams p;
+        p.out = g->probe;
+        p.ldo = D;
+        p.accumulate = acc;
+        CK(gemm_f32_generic(dqp, D, 1, w->in_proj_w, 1, D, 1, D, D, EPI_F32, DT_F32, p, s));
+      }
+    }
+    // k,v projections: dlast (+)= dkv · Wkv ; dWkv = dkvᵀ · last_lp
+    if (d_last_hidden) CK(copy_f32(d_last_hidden, dlast_buf, (size_t)M * D, s));
+    {
+      EpiParams p;
+      p.out = dlast_buf;
+      p.ldo = D;
+      p.accumulate = d_last_hidden ? 1 : 0;
+      CK(gemm_nt(ctx, dkv, 2 * D, at(shadow, ctx->sh_hwkv_t), 2 * D, M, D, 2 * D, EPI_F32, DT_F32, p, s));
+    }
+    if (g->in_proj_w)
+      CK(gemm_tn(ctx, dkv, 2 * D, act + lay.a_lastlp, D, M, 2 * D, D, g->in_proj_w + (size_t)D * D, D, acc, s));
+    if (g->in_proj_b) RET(bias_grad(ctx, lay, ws, dkv, 2 * D, M, 2 * D, 2 * D, g->in_proj_b + D, acc, s));
+    dlast = dlast_buf;
+  }
+
+  // post_layernorm backward -> dx (fp32) and its low-precision copy (A operand of the last block's GEMMs)
+  if (dlast) {
+    RET(ln_backward(ctx, lay, ws, dlast, DT_F32, hsL, reinterpret_cast<const float*>(act + lay.a_pstats), M,
+                    w->post_ln_w, d_tap_last, dx, gbuf, g->post_ln_w, g->post_ln_b, acc, s));
+  } else if (d_tap_last) {
+    CK(copy_f32(d_tap_last, dx, (size_t)M * D, s));
+    CK(cast_f32(d_tap_last, gbuf, dt, (size_t)M * D, s));
+  } else {
+    CK(hipMemsetAsync(dx, 0, (size_t)M * D * 4, s));
+    CK(hipMemsetAsync(gbuf, 0, (size_t)M * D * ctx->es, s));
+  }
+  return SGL_OK;
+}
+
+int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
+                       int H, int W, const float* hidden_states, const float* d_tap, int need_dx, const void* saved,
+                       size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  if (!ctx || !w || !shadow || !g || !hidden_states || !g->layers) return SGL_ERR_NULL;
+  if (layer < 0 || layer >= ctx->L) return SGL_ERR_BAD_SHAPE;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  Layout lay(ctx, B, H, W, true);
+  RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh,
+            DP = ctx->DP;
+  const int acc = g->accumulate;
+  const sgl_layer_weights& lw = w->layers[layer];
+  const sgl_layer_grads& lg = g->layers[layer];
+  const ShadowLayer& sl = ctx->sh_layers[layer];
+  const char* lb = reinterpret_cast<const char*>(saved) + lay.layer_base(layer);
+  const float* x_in = hidden_states + (size_t)layer * M * D;
+  const float* xmid = reinterpret_cast<const float*>(lb + lay.r_xmid);
+  float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
+  void* gbuf = at(ws, lay.w_g);
+  void* du = at(ws, lay.w_du);
+  void* dhb = at(ws, lay.w_dh);
+  void* dqkv = at(ws, lay.w_dqkv);
+
+  // ---- MLP: x_out = xmid + fc2(gelu(fc1(LN2 xmid)))          gbuf = lowp(d x_out)
+  {
+    EpiParams p;
+    p.out = du;
+    p.ldo = Ip;
+    p.aux = lb + lay.r_u;
+    p.ldaux = Ip;
+    CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.w2_t), D, M, Ip, D, EPI_GELU_BWD, dt, p, s));
+  }
+  if (lg.fc2_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_a, Ip, M, D, I, lg.fc2_w, I, acc, s));
+  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, lg.fc2_b, acc, s));
+  {
+    EpiParams p;
+    p.out = dhb;
+    p.ldo = D;
+    CK(gemm_nt(ctx, du, Ip, at(shadow, sl.w1_t), Ip, M, D, Ip, EPI_STORE, dt, p, s));
+  }
+  if (lg.fc1_w) CK(gemm_tn(ctx, du, Ip, lb + lay.r_h2, D, M, I, D, lg.fc1_w, D, acc, s));
+  RET(bias_grad(ctx, lay, ws, du, Ip, M, Ip, I, lg.fc1_b, acc, s));
+  // LN2 backward: dx := dx + LN2'(dh2);  gbuf := lowp(dx)
+  RET(ln_backward(ctx, lay, ws, dhb, dt, xmid, reinterpret_cast<const float*>(lb + lay.r_stats2), M, lw.ln2_w, dx, dx,
+                  gbuf, lg.ln2_w, lg.ln2_b, acc, s));
+
+  // ---- attention: xmid = x_in + out_proj(attn(qkv(LN1 x_in)))
+  {
+    EpiParams p;
+    p.out = dhb;  // d attn
+    p.ldo = D;
+    CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.wo_t), D, M, D, D, EPI_STORE, dt, p, s));
+  }
+  if (lg.o_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_attn, D, M, D, D, lg.o_w, D, acc, s));
+  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, lg.o_b, acc, s));
+  {
+    const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
+    const char* q = lb + lay.r_qkv;
+    CK(attn_bwd(q, q + hsz, q + 2 * hsz, lb + lay.r_attn, dhb, reinterpret_cast<const float*>(lb + lay.r_lse), dt, dqkv,
+                reinterpret_cast<float*>(at(ws, lay.w_delta)), nullptr, B, Hh, N, dh, DP, s));
+  }
+  {
+    float* gw[3] = {lg.q_w, lg.k_w, lg.v_w};
+    float* gb[3] = {lg.q_b, lg.k_b, lg.v_b};
+    for (int j = 0; j < 3; ++j) {
+      const char* aj = reinterpret_cast<const char*>(dqkv) + (size_t)j * D * ctx->es;
+      if (gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s));
+      RET(bias_grad(ctx, lay, ws, aj, 3 * D, M, D, D, gb[j], acc, s));
+    }
+  }
+  if (d_tap) CK(add_f32(dx, d_tap, dx, (size_t)M * D, s));
+  const bool ln1_params = lg.ln1_w || lg.ln1_b;
+  if (need_dx || ln1_params) {
+    EpiParams p;
+    p.out = dhb;  // d LN1 output
+    p.ldo = D;
+    CK(gemm_nt(ctx, dqkv, 3 * D, at(shadow, sl.wqkv_t), 3 * D, M, D, 3 * D, EPI_STORE, dt, p, s));
+    RET(ln_backward(ctx, lay, ws, dhb, dt, x_in, reinterpret_cast<const float*>(lb + lay.r_stats1), M, lw.ln1_w, dx, dx,
+                    gbuf, lg.ln1_w, lg.ln1_b, acc, s));
+  }
+  return SGL_OK;
+}
+
+int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, int B, int H, int W, int interpolate_pos,
+                       const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  if (!ctx || !w || !g) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  Layout lay(ctx, B, H, W, true);
+  RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = ctx->D, M = lay.M, N = lay.N;
+  const int acc = g->accumulate;
+  const char* act = reinterpret_cast<const char*>(saved);
+  float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
+  void* gbuf = at(ws, lay.w_g);  // low-precision copy of dx (written by the last LN1 backward / begin)
+  if (g->patch_w) CK(gemm_tn(ctx, gbuf, D, act + lay.a_im2col, ctx->Kp, M, D, ctx->K0, g->patch_w, ctx->K0, acc, s));
+  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, g->patch_b, acc, s));
+  if (g->pos) {
+    if (lay.gh == ctx->g0 && lay.gw == ctx->g0) {
+      CK(batch_sum(dx, B, (size_t)N * D, g->pos, acc, s));
+    } else {
+      float* dpos = reinterpret_cast<float*>(at(ws, lay.w_dlast));  // [N][D] scratch
+      CK(batch_sum(dx, B, (size_t)N * D, dpos, 0, s));
+      if (!acc) CK(hipMemsetAsync(g->pos, 0, (size_t)ctx->g0 * ctx->g0 * D * 4, s));
+      CK(pos_resize_bwd(dpos, lay.gh, lay.gw, g->pos, ctx->g0, D, s));
+    }
+  }
+  (void)interpolate_pos;
+  return SGL_OK;
+}
+
+int sgl_backward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                 int interpolate_pos, const float* hidden_states, const float* const* d_taps,
+                 const float* d_last_hidden, const float* d_pooled, int first_trainable_block, int train_embeddings,
+                 const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  if (!ctx) return SGL_ERR_NULL;
+  const int L = ctx->L;
+  RET(sgl_backward_begin(ctx, w, shadow, g, B, H, W, hidden_states, d_last_hidden, d_pooled,
+                         d_taps ? d_taps[L] : nullptr, saved, saved_bytes, ws, ws_bytes, stream));
+  int stop = train_embeddings ? 0 : first_trainable_block;
+  if (stop < 0) stop = 0;
+  for (int l = L - 1; l >= stop; --l) {
+    const int need_dx = (l > stop) || train_embeddings;
+    RET(sgl_backward_layer(ctx, w, shadow, g, l, B, H, W, hidden_states, d_taps ? d_taps[l] : nullptr, need_dx, saved,
+                           saved_bytes, ws, ws_bytes, stream));
+  }
+  if (train_embeddings)
+    RET(sgl_backward_embed(ctx, w, g, B, H, W, interpolate_pos, saved, saved_bytes, ws, ws_bytes, stream));
+  return SGL_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// single-kernel entry points
+// -------------------------------------------------------------------------------------------------------
+#define CKV(expr)                                   \
+  do {                                              \
+    hipError_t e_ = (expr);                         \
+    if (e_ == hipErrorInvalidValue) return SGL_ERR_UNSUPPORTED; \
+    if (e_ != hipSuccess) return SGL_ERR_HIP;       \
+  } while (0)
+
+int sgl_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                         float* rstd, int M, int D, float eps, sgl_stream stream) {
+  CKV(layernorm_fwd(x, gamma, beta, y, y_dtype, D, mean, rstd, M, D, eps, (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* dres, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                         float* dbeta, float* scratch, size_t scratch_bytes, int M, int D, sgl_stream stream) {
+  const int nblk = layernorm_bwd_blocks(M);
+  if (scratch_bytes < (size_t)nblk * 2 * D * 4) return SGL_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  CKV(layernorm_bwd(dy, dy_dtype, D, x, mean, rstd, gamma, dres, dx, dx_lp, lp_dtype, scratch, nblk, M, D, s));
+  if (dgamma) CKV(reduce_partials(scratch, nblk, 2 * D, dgamma, D, 0, s));
+  if (dbeta) CKV(reduce_partials(scratch + D, nblk, 2 * D, dbeta, D, 0, s));
+  return SGL_OK;
+}
+
+int sgl_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* out,
+                   int ldo, void* out2, int ldo2, const float* bias, const float* res, int ldr, const void* aux,
+                   int ldaux, const float* pos, int pos_rows, int tokens, int heads, int head_dim, int head_dim_pad,
+                   int batch, sgl_stream stream) {
+  EpiParams p;
+  p.out = out; p.ldo = ldo; p.out2 = out2; p.ldo2 = ldo2; p.bias = bias; p.res = res; p.ldr = ldr;
+  p.aux = aux; p.ldaux = ldaux; p.pos = pos; p.pos_rows = pos_rows > 0 ? pos_rows : 1;
+  p.tokens = tokens > 0 ? tokens : 1; p.heads = heads > 0 ? heads : 1; p.head_dim = head_dim > 0 ? head_dim : 8;
+  p.head_dim_pad = head_dim_pad > 0 ? head_dim_pad : 8; p.batch = batch > 0 ? batch : 1;
+  const bool f32_out = (epi == EPI_RES_F32 || epi == EPI_POS_F32 || epi == EPI_F32);
+  const int out_dt = f32_out ? DT_F32 : dtype;
+  if (dtype == DT_BF16)
+    CKV(gemm_nt_bf16(A, lda, B, ldb, M, N, K, epi, out_dt, p, (hipStream_t)stream));
+  else
+    CKV(gemm_f32_generic((const float*)A, lda, 1, (const float*)B, ldb, 1, M, N, K, epi, out_dt, p,
+                         (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
+                   float* out, int ldo, int accumulate, sgl_stream stream) {
+  EpiParams p;
+  p.out = out; p.ldo = ldo; p.accumulate = accumulate;
+  if (dtype == DT_BF16)
+    CKV(gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, (hipStream_t)stream));
+  else
+    CKV(gemm_f32_generic((const float*)A, 1, lda, (const float*)B, 1, ldb, N1, N2, Mred, EPI_F32, DT_F32, p,
+                         (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
+                    int head_dim, int head_dim_pad, sgl_stream stream) {
+  CKV(attn_fwd(q, k, v, dtype, out, lse, B, H, N, head_dim, head_dim_pad, (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                    const float* lse, void* dqkv, float* delta_scratch, int B, int H, int N, int head_dim,
+                    int head_dim_pad, sgl_stream stream) {
+  CKV(attn_bwd(q, k, v, out, dout, lse, dtype, dqkv, delta_scratch, nullptr, B, H, N, head_dim, head_dim_pad,
+               (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_colsum(int dtype, const void* in, int ld, int M, int N, float* out, int accumulate, float* scratch,
+                  size_t scratch_bytes, sgl_stream stream) {
+  if (scratch_bytes < (size_t)colsum_chunks(M) * N * 4) return SGL_ERR_WORKSPACE;
+  CKV(colsum(in, dtype, ld, M, N, N, scratch, out, accumulate, (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_im2col(const float* pixels, int channels_last, void* out, int out_dtype, int B, int H, int W, int P, int Kp,
+                  sgl_stream stream) {
+  CKV(im2col(pixels, channels_last, out, out_dtype, B, H, W, P, Kp, (hipStream_t)stream));
+  return SGL_OK;
+}
+
+int sgl_op_pos_resize(const float* table, int native_grid, float* out, int gh, int gw, int D, sgl_stream stream) {
+  CKV(pos_resize(table, native_grid, out, gh, gw, D, (hipStream_t)stream));
+  return SGL_OK;
+}
+
+}  // extern "C"

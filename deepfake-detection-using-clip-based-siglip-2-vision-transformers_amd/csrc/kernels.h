@@ -1,0 +1,97 @@
+// Internal launch API shared by the kernel translation units and the C-ABI host code (encoder.cpp).
+// Every launcher enqueues on the stream it is given, allocates nothing and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sgl {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+static inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+// ---- GEMM epilogues (shared by the MFMA kernels and the strict-fp32 generic kernel) ----------------
+enum Epi : int {
+  EPI_STORE = 0,      // out[T]   = alpha*acc (+bias)
+  EPI_BIAS_GELU = 1,  // out[T]   = u = acc+bias ; out2[T] = gelu_tanh(u)
+  EPI_RES_F32 = 2,    // out[f32] = res + acc + bias
+  EPI_QKV = 3,        // head-major scatter of acc+bias: out[which][B][H][tokens][head_dim_pad]  (T)
+  EPI_GELU_BWD = 4,   // out[T]   = acc * gelu_tanh'(aux[row,col])
+  EPI_POS_F32 = 5,    // out[f32] = acc + bias + pos[row % pos_rows, col]
+  EPI_F32 = 6,        // out[f32] = alpha*acc (+bias) (+out if accumulate) ; atomicAdd when atomic != 0
+};
+
+struct EpiParams {
+  void* out = nullptr;   int ldo = 0;
+  void* out2 = nullptr;  int ldo2 = 0;
+  const float* bias = nullptr;
+  const float* res = nullptr;  int ldr = 0;
+  const void* aux = nullptr;   int ldaux = 0;
+  const float* pos = nullptr;  int pos_rows = 1;
+  int tokens = 1, heads = 1, head_dim = 8, head_dim_pad = 8, batch = 1;
+  float alpha = 1.0f;
+  int accumulate = 0;
+  int atomic = 0;
+};
+
+// ---- layernorm.hip -----------------------------------------------------------------------------------
+hipError_t layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, int ldy,
+                         float* mean, float* rstd, int M, int D, float eps, hipStream_t s);
+int layernorm_bwd_blocks(int M);
+// partial: [nblk][2*D] floats (dgamma then dbeta per block)
+hipError_t layernorm_bwd(const void* dy, int dy_dtype, int lddy, const float* x, const float* mean,
+                         const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_lp,
+                         int lp_dtype, float* partial, int nblk, int M, int D, hipStream_t s);
+// out[j] (+)= sum_b partial[b*stride + j], j < n
+hipError_t reduce_partials(const float* partial, int nblk, int stride, float* out, int n, int accumulate,
+                           hipStream_t s);
+
+// ---- elementwise.hip ---------------------------------------------------------------------------------
+hipError_t im2col(const float* pix, int channels_last, void* out, int out_dtype, int B, int H, int W, int P,
+                  int Kp, hipStream_t s);
+// dst[r][c] (row stride ldd) = cast(src[r][c]) for r < Rp, c < Cp, zero outside src's R x C
+hipError_t cast_pad(const float* src, int R, int C, int lds_, void* dst, int dst_dtype, int Rp, int Cp, int ldd,
+                    hipStream_t s);
+// dst[c][r] (row stride ldd) = cast(src[r][c]) for c < Cp, r < Rp, zero outside
+hipError_t cast_transpose_pad(const float* src, int R, int C, int lds_, void* dst, int dst_dtype, int Cp, int Rp,
+                              int ldd, hipStream_t s);
+int colsum_chunks(int M);
+// out[j] (+)= sum_r in[r][j] for j < n_out (n_out <= N; N, ld multiples of 8; columns up to N are read)
+hipError_t colsum(const void* in, int dtype, int ld, int M, int N, int n_out, float* partial /*[chunks][N]*/,
+                  float* out, int accumulate, hipStream_t s);
+hipError_t batch_sum(const float* in, int B, size_t n, float* out, int accumulate, hipStream_t s);
+hipError_t pos_resize(const float* table, int g0, float* out, int gh, int gw, int D, hipStream_t s);
+hipError_t pos_resize_bwd(const float* dout, int gh, int gw, float* dtable, int g0, int D, hipStream_t s);
+hipError_t copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
+hipError_t cast_f32(const float* src, void* dst, int dst_dtype, size_t n, hipStream_t s);
+hipError_t add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t s);  // b may be null
+// attention-pool (1 query per image): q [H*dh] fp32, K/V head-major [B][H][N][DP]
+hipError_t pool_attn_fwd(const float* q, const void* K, const void* V, int dtype, void* out /*[B][H*dh]*/,
+                         float* probs /*[B][H][N]*/, int B, int H, int N, int dh, int DP, hipStream_t s);
+hipError_t pool_attn_bwd(const float* q, const void* K, const void* V, int dtype, const float* probs,
+                         const float* dout /*[B][H*dh] fp32*/, void* dkv /*[B*N][2*H*dh] T*/,
+                         float* dq_partial /*[B][H*dh]*/, int B, int H, int N, int dh, int DP, hipStream_t s);
+
+// ---- gemm_f32.hip: strict-mode generic strided GEMM  C[m,n] = sum_k A(m,k)*B(n,k) ---------------------
+hipError_t gemm_f32_generic(const float* A, long sam, long sak, const float* B, long sbn, long sbk, int M, int N,
+                            int K, int epi, int out_dtype, const EpiParams& p, hipStream_t s);
+
+// ---- gemm_bf16.hip: MFMA kernels ----------------------------------------------------------------------
+// NT: C[M,N] = A[M,K] * B[N,K]^T ; A,B bf16 K-contiguous, lda/ldb multiples of 8, K multiple of 8
+hipError_t gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
+                        int out_dtype, const EpiParams& p, hipStream_t s);
+// TN: C[N1,N2] (+)= sum_m A[m,n1] * B[m,n2] ; fp32 output via EPI_F32 (accumulate / atomic split-K)
+hipError_t gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
+                        const EpiParams& p, hipStream_t s);
+
+// ---- attention.hip -------------------------------------------------------------------------------------
+// q,k,v: head-major [B][H][N][DP]; out: token-major [B*N][H*dh]; lse: [B][H][N] (natural log units)
+hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void* out, float* lse, int B, int H,
+                    int N, int dh, int DP, hipStream_t s);
+// dout: token-major [B*N][H*dh] (T); dqkv: token-major [B*N][3*H*dh] (T); delta: [B][H][N] scratch
+hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                    const float* lse, int dtype, void* dqkv, float* delta, float* reserved, int B, int H, int N,
+                    int dh, int DP, hipStream_t s);
+size_t attn_bwd_scratch_bytes(int dtype, int B, int H, int N, int dh, int DP);
+
+}  // namespace sgl

@@ -1,0 +1,505 @@
+"""Host-side mirror of the two call surfaces the reference uses for the encoder, backed by the
+hand-written gfx950 kernels in ``libsiglip_hip.so``.
+
+Surface H (HuggingFace-style; ``Siglip2sidafrozen.py:753,757-768,771,787-793``):
+    ``SiglipVisionModelHIP.from_pretrained(path_or_name)``, ``model(pixel_values=..., output_hidden_states=True,
+    interpolate_pos_encoding=True)`` → ``.pooler_output`` / ``.last_hidden_state`` / ``.hidden_states``;
+    ``.config.hidden_size``; ``.vision_model.embeddings`` / ``.vision_model.encoder.layers[i]`` for freezing;
+    ``state_dict`` keys equal HF ``SiglipVisionModel`` keys.
+Surface O (open_clip-style; ``cifake_binary_classifier.py:625-638,721``, ``hidf_video_classifier.py:259-273,307``):
+    ``create_model_and_transforms(name, pretrained, device)`` → ``(model, None, preprocess)``;
+    ``model.encode_image(x)`` → un-normalised (B, D); ``model.embed_dim``.
+
+PyTorch is plumbing only (device memory, streams, autograd graph).  All arithmetic of the encoder runs in the
+HIP library; there is no CPU fallback — calling the model on a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+from .config import SiglipVisionConfig, get_config, NAMED_CONFIGS
+from .weights import seeded_state_dict
+
+
+# ---------------------------------------------------------------------------------------------------------
+# parameter holders: same module tree / names as HF SiglipVisionModel (TF:modeling_siglip.py:116-135,
+# 253-271,309-316,324-331,560-571,622-631) so state_dict keys and the reference's freezing code line up
+# ---------------------------------------------------------------------------------------------------------
+class _Affine(nn.Module):
+    def __init__(self, out_f, in_shape=None, bias=True):
+        super().__init__()
+        shape = (out_f,) if in_shape is None else (out_f, *in_shape)
+        self.weight = nn.Parameter(torch.zeros(shape))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_f))
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = _Affine(d, (d,))
+        self.v_proj = _Affine(d, (d,))
+        self.q_proj = _Affine(d, (d,))
+        self.out_proj = _Affine(d, (d,))
+
+
+class _MLPParams(nn.Module):
+    def __init__(self, d, i):
+        super().__init__()
+        self.fc1 = _Affine(i, (d,))
+        self.fc2 = _Affine(d, (i,))
+
+
+class _LayerParams(nn.Module):
+    def __init__(self, d, i):
+        super().__init__()
+        self.layer_norm1 = _Affine(d)
+        self.self_attn = _AttnParams(d)
+        self.layer_norm2 = _Affine(d)
+        self.mlp = _MLPParams(d, i)
+
+
+class _EncoderParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([_LayerParams(cfg.hidden_size, cfg.intermediate_size)
+                                     for _ in range(cfg.num_hidden_layers)])
+
+
+class _EmbeddingParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.patch_embedding = _Affine(cfg.hidden_size, (3, cfg.patch_size, cfg.patch_size))
+        self.position_embedding = _Affine(cfg.num_positions, (cfg.hidden_size,), bias=False)
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.zeros(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Affine(d, (d,))
+
+
+class _HeadParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.hidden_size
+        self.probe = nn.Parameter(torch.zeros(1, 1, d))
+        self.attention = _MHAParams(d)
+        self.layernorm = _Affine(d)
+        self.mlp = _MLPParams(d, cfg.intermediate_size)
+
+
+@dataclass
+class VisionModelOutput:
+    """Fields of HF ``BaseModelOutputWithPooling`` the reference reads (``Siglip2sidafrozen.py:788-793``)."""
+    last_hidden_state: torch.Tensor
+    pooler_output: Optional[torch.Tensor]
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.pooler_output, self.hidden_states)[i]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# autograd bridge
+# ---------------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    """One autograd node for the whole encoder.  Inputs: pixels + every parameter (fixed order, see
+    ``SiglipVisionModelHIP._flat_params``).  Outputs: pooled, last_hidden_state, then the requested
+    hidden-state taps as separate tensors (so unused taps cost no gradient memory)."""
+
+    @staticmethod
+    def forward(ctx, mod, train, interp, want_pooled, tap_ids, pixel_values, *params):
+        L, D = mod.config.num_hidden_layers, mod.config.hidden_size
+        lib = _lib.load()
+        px = pixel_values
+        if px.dim() != 4 or px.shape[1] != 3:
+            raise ValueError(f"pixel_values must be (B,3,H,W), got {tuple(px.shape)}")
+        if px.dtype != torch.float32:
+            px = px.float()
+        channels_last = 0
+        if not px.is_contiguous():
+            if px.is_contiguous(memory_format=torch.channels_last):
+                channels_last = 1
+            else:
+                px = px.contiguous()
+        B, _, H, W = px.shape
+        P = mod.config.patch_size
+        if H < P or W < P:
+            raise ValueError(f"image size ({H},{W}) is smaller than patch_size {P}")
+        gh, gw = H // P, W // P
+        N, M = gh * gw, B * gh * gw
+        if (gh, gw) != (mod.config.native_grid, mod.config.native_grid) and not interp:
+            raise ValueError(f"Input image size ({H}*{W}) doesn't match model native "
+                             f"({mod.config.image_size}*{mod.config.image_size}); pass interpolate_pos_encoding=True")
+        dev = px.device
+        shadow, weights = mod._prepared(dev)
+        sizes = mod._sizes(B, H, W, train)
+        keep_all = train or len(tap_ids) > 0
+        hs_slots = L + 1 if keep_all else 2
+        hs = torch.empty((hs_slots, M, D), dtype=torch.float32, device=dev)
+        last = torch.empty((M, D), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, D), dtype=torch.float32, device=dev) if want_pooled else None
+        saved = torch.empty(sizes[1], dtype=torch.uint8, device=dev) if train else None
+        ws = None if train else torch.empty(sizes[2], dtype=torch.uint8, device=dev)
+        st = lib.sgl_forward(mod._ctx, C.byref(weights), shadow.data_ptr(), px.data_ptr(), channels_last, B, H, W,
+                             1 if interp else 0, hs.data_ptr(), hs_slots, last.data_ptr(), _lib.ptr(pooled),
+                             _lib.ptr(saved), sizes[1] if train else 0, _lib.ptr(ws), 0 if train else sizes[2],
+                             _lib.current_stream_handle())
+        _lib.check(st, "sgl_forward", mod._ctx)
+        if train:
+            ctx.mod, ctx.saved, ctx.hs, ctx.geom, ctx.interp = mod, saved, hs, (B, H, W, N, M), interp
+            ctx.tap_ids, ctx.want_pooled, ctx.weights, ctx.shadow = tap_ids, want_pooled, weights, shadow
+        outs = [pooled if want_pooled else last.new_zeros(()), last.view(B, N, D)]
+        outs += [hs[i].view(B, N, D) for i in tap_ids]
+        if not want_pooled:
+            ctx.mark_non_differentiable(outs[0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_pooled, d_last, *d_taps):
+        mod = ctx.mod
+        lib = _lib.load()
+        cfg = mod.config
+        L, D = cfg.num_hidden_layers, cfg.hidden_size
+        B, H, W, N, M = ctx.geom
+        dev = ctx.hs.device
+        needs = ctx.needs_input_grad[6:]
+        names = mod._flat_names
+        params = mod._flat_params()
+
+        def prep(g):
+            if g is None:
+                return None
+            g = g.float() if g.dtype != torch.float32 else g
+            return g.contiguous()
+
+        d_pooled = prep(d_pooled) if ctx.want_pooled else None
+        d_last = prep(d_last)
+        tap_grads = [None] * (L + 1)
+        for i, g in zip(ctx.tap_ids, d_taps):
+            if g is not None:
+                g = prep(g)
+                tap_grads[i] = g if tap_grads[i] is None else tap_grads[i] + g
+
+        # gradient buffers: one flat fp32 bucket per group (embeddings, each block, post-LN + head)
+        grads_out = [None] * len(params)
+        groups: dict[str, list[int]] = {}
+        for idx, (grp, field) in enumerate(names):
+            if needs[idx]:
+                groups.setdefault(grp, []).append(idx)
+        buckets: dict[str, torch.Tensor] = {}
+        for grp, idxs in groups.items():
+            total = sum(params[i].numel() for i in idxs)
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            off = 0
+            for i in idxs:
+                n = params[i].numel()
+                grads_out[i] = flat[off:off + n].view(params[i].shape)
+                off += n
+            buckets[grp] = flat
+
+        gl = (_lib.SglLayerPtrs * max(L, 1))()
+        g = _lib.SglGrads()
+        g.layers = C.cast(gl, C.POINTER(_lib.SglLayerPtrs))
+        g.accumulate = 0
+        for idx, (grp, field) in enumerate(names):
+            p = None if grads_out[idx] is None else grads_out[idx].data_ptr()
+            if grp.startswith("layer"):
+                setattr(gl[int(grp[5:])], field, p)
+            else:
+                setattr(g, field, p)
+
+        train_emb = "emb" in groups
+        layer_ids = sorted(int(k[5:]) for k in groups if k.startswith("layer"))
+        first = layer_ids[0] if layer_ids else L
+        stop = 0 if train_emb else first
+        sizes = mod._sizes(B, H, W, True)
+        ws = torch.empty(sizes[2], dtype=torch.uint8, device=dev)
+        stream = _lib.current_stream_handle()
+        wts, shadow = ctx.weights, ctx.shadow
+        reducer = mod._grad_reducer
+        st = lib.sgl_backward_begin(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), B, H, W, ctx.hs.data_ptr(),
+                                    _lib.ptr(d_last), _lib.ptr(d_pooled), _lib.ptr(tap_grads[L]),
+                                    ctx.saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
+        _lib.check(st, "sgl_backward_begin", mod._ctx)
+        if reducer is not None and "head" in buckets:
+            reducer.reduce_bucket(buckets["head"])
+        for l in range(L - 1, stop - 1, -1):
+            need_dx = 1 if (l > stop or train_emb) else 0
+            st = lib.sgl_backward_layer(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), l, B, H, W,
+                                        ctx.hs.data_ptr(), _lib.ptr(tap_grads[l]), need_dx, ctx.saved.data_ptr(),
+                                        sizes[1], ws.data_ptr(), sizes[2], stream)
+            _lib.check(st, f"sgl_backward_layer[{l}]", mod._ctx)
+            if reducer is not None and f"layer{l}" in buckets:
+                reducer.reduce_bucket(buckets[f"layer{l}"])
+        if train_emb:
+            st = lib.sgl_backward_embed(mod._ctx, C.byref(wts), C.byref(g), B, H, W, 1 if ctx.interp else 0,
+                                        ctx.saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
+            _lib.check(st, "sgl_backward_embed", mod._ctx)
+            if reducer is not None:
+                reducer.reduce_bucket(buckets["emb"])
+        if reducer is not None:
+            reducer.finish()
+        ctx.saved = ctx.hs = None
+        return (None, None, None, None, None, None, *grads_out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# surface H
+# ---------------------------------------------------------------------------------------------------------
+class SiglipVisionModelHIP(nn.Module):
+    """Drop-in for ``transformers.SiglipVisionModel`` on the reference's path (see module docstring)."""
+
+    def __init__(self, config, compute_dtype: str = "bf16"):
+        super().__init__()
+        self.config = get_config(config)
+        if compute_dtype not in ("bf16", "fp32"):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self.compute_dtype = compute_dtype
+        cfg = self.config
+        self.embeddings = _EmbeddingParams(cfg)
+        self.encoder = _EncoderParams(cfg)
+        self.post_layernorm = _Affine(cfg.hidden_size)
+        self.use_head = bool(cfg.vision_use_head)
+        if self.use_head:
+            self.head = _HeadParams(cfg)
+        self._ctx = None
+        self._shadow = None
+        self._shadow_key = None
+        self._weights_struct = None
+        self._weights_keep = None
+        self._weights_key = None
+        self._size_cache: dict = {}
+        self._grad_reducer = None
+        self._gradient_checkpointing = False
+        self._flat_names = self._build_names()
+
+    # ---- HF surface ------------------------------------------------------------------------------------
+    @property
+    def vision_model(self):
+        """transformers-4.x layout alias used by the reference's freezing code
+        (``Siglip2sidafrozen.py:757,762``): ``encoder.vision_model.embeddings`` / ``.encoder.layers``."""
+        return self
+
+    @classmethod
+    def from_pretrained(cls, name_or_path: str, compute_dtype: str = "bf16", seed: int = 0):
+        """Local directory (``config.json`` + ``model.safetensors``), a ``.safetensors`` file next to a
+        ``config.json``, or a known config name.  There is no network: a bare name gives the closed-form
+        seeded initialisation of that architecture (``weights.seeded_state_dict``)."""
+        if os.path.isdir(name_or_path):
+            with open(os.path.join(name_or_path, "config.json")) as f:
+                raw = json.load(f)
+            raw = raw.get("vision_config", raw)
+            fields = SiglipVisionConfig.__dataclass_fields__
+            cfg = SiglipVisionConfig(**{k: v for k, v in raw.items() if k in fields})
+            model = cls(cfg, compute_dtype)
+            from safetensors.torch import load_file
+            model.load_state_dict(load_file(os.path.join(name_or_path, "model.safetensors")))
+            return model
+        if name_or_path in NAMED_CONFIGS:
+            model = cls(get_config(name_or_path), compute_dtype)
+            model.load_state_dict(seeded_state_dict(model.config, seed))
+            return model
+        raise OSError(f"{name_or_path} is neither a local checkpoint directory nor a known config name "
+                      f"(no network access); known: {sorted(NAMED_CONFIGS)}")
+
+    def gradient_checkpointing_enable(self, **_):
+        """Accepted for interface parity (``Siglip2sidafrozen.py:1195-1196``).  Activations for a 64-image
+        so400m batch (≈52 GB) fit the 288 GB of HBM3E, so nothing is recomputed."""
+        self._gradient_checkpointing = True
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {}
+        for k, v in state_dict.items():
+            k2 = k[len("vision_model."):] if k.startswith("vision_model.") else k
+            sd[k2] = v
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def forward(self, pixel_values, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
+                hidden_state_ids=None, **_):
+        if pixel_values.device.type != "cuda":
+            raise RuntimeError("SiglipVisionModelHIP runs only on an AMD GPU through libsiglip_hip.so "
+                               "(no CPU fallback); move the model and pixel_values to 'cuda'")
+        L = self.config.num_hidden_layers
+        if hidden_state_ids is not None:
+            tap_ids = tuple(int(i) % (L + 1) for i in hidden_state_ids)
+        elif output_hidden_states:
+            tap_ids = tuple(range(L + 1))
+        else:
+            tap_ids = ()
+        params = self._flat_params()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _EncoderFn.apply(self, train, bool(interpolate_pos_encoding), self.use_head, tap_ids, pixel_values,
+                                *params)
+        pooled = outs[0] if self.use_head else None
+        hs = tuple(outs[2:]) if tap_ids else None
+        if hs is not None and hidden_state_ids is None and output_hidden_states:
+            pass
+        return VisionModelOutput(last_hidden_state=outs[1], pooler_output=pooled, hidden_states=hs)
+
+    # ---- plumbing ----------------------------------------------------------------------------------------
+    def _build_names(self):
+        names = [("emb", "patch_w"), ("emb", "patch_b"), ("emb", "pos")]
+        for l in range(self.config.num_hidden_layers):
+            names += [(f"layer{l}", f) for f in _lib.LAYER_FIELDS]
+        names += [("head", "post_ln_w"), ("head", "post_ln_b")]
+        if self.use_head:
+            names += [("head", f) for f in _lib.HEAD_FIELDS]
+        return names
+
+    def _flat_params(self):
+        e = self.embeddings
+        ps = [e.patch_embedding.weight, e.patch_embedding.bias, e.position_embedding.weight]
+        for lyr in self.encoder.layers:
+            a, m = lyr.self_attn, lyr.mlp
+            ps += [lyr.layer_norm1.weight, lyr.layer_norm1.bias, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight,
+                   a.k_proj.bias, a.v_proj.weight, a.v_proj.bias, a.out_proj.weight, a.out_proj.bias,
+                   lyr.layer_norm2.weight, lyr.layer_norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        ps += [self.post_layernorm.weight, self.post_layernorm.bias]
+        if self.use_head:
+            h = self.head
+            ps += [h.probe, h.attention.in_proj_weight, h.attention.in_proj_bias, h.attention.out_proj.weight,
+                   h.attention.out_proj.bias, h.layernorm.weight, h.layernorm.bias, h.mlp.fc1.weight, h.mlp.fc1.bias,
+                   h.mlp.fc2.weight, h.mlp.fc2.bias]
+        return ps
+
+    def _ensure_ctx(self):
+        if self._ctx is None:
+            lib = _lib.load()
+            cfg = self.config
+            c = _lib.SglConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                               cfg.patch_size, cfg.native_grid, cfg.layer_norm_eps,
+                               _lib.SGL_DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.SGL_DTYPE_F32,
+                               1 if self.use_head else 0)
+            ctx = lib.sgl_create(C.byref(c))
+            if not ctx:
+                raise _lib.SglError(f"sgl_create: unsupported configuration {cfg}")
+            self._ctx = ctx
+        return self._ctx
+
+    def _sizes(self, B, H, W, train):
+        key = (B, H, W, bool(train))
+        if key not in self._size_cache:
+            lib = _lib.load()
+            a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            st = lib.sgl_query_sizes(self._ensure_ctx(), B, H, W, 1 if train else 0, C.byref(a), C.byref(b), C.byref(c))
+            _lib.check(st, "sgl_query_sizes", self._ctx)
+            self._size_cache[key] = (a.value, b.value, c.value)
+        return self._size_cache[key]
+
+    def _build_weights_struct(self, params):
+        L = self.config.num_hidden_layers
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("encoder master parameters must be contiguous fp32 (the HIP path keeps its own "
+                                   "bf16 shadows); do not call .half()/.bfloat16() on the encoder")
+        layers = (_lib.SglLayerPtrs * max(L, 1))()
+        w = _lib.SglWeights()
+        w.layers = C.cast(layers, C.POINTER(_lib.SglLayerPtrs))
+        for (grp, field), p in zip(self._flat_names, params):
+            if grp.startswith("layer"):
+                setattr(layers[int(grp[5:])], field, p.data_ptr())
+            else:
+                setattr(w, field, p.data_ptr())
+        return w, layers
+
+    def _prepared(self, dev):
+        """(shadow arena, weights struct), refreshed when any master parameter changed (optimizer step,
+        load_state_dict, EMA swap of ``param.data`` — ``cifake_binary_classifier.py:227-236``)."""
+        lib = _lib.load()
+        self._ensure_ctx()
+        params = self._flat_params()
+        if params[0].device != dev:
+            raise RuntimeError(f"model is on {params[0].device}, input on {dev}")
+        ptr_key = tuple(p.data_ptr() for p in params)
+        ver_key = tuple(p._version for p in params)
+        if self._weights_struct is None or self._weights_key != ptr_key:
+            self._weights_struct, self._weights_keep = self._build_weights_struct(params)
+            self._weights_key = ptr_key
+        key = (ptr_key, ver_key)
+        if self._shadow is None or self._shadow.device != dev or self._shadow_key != key:
+            nbytes = self._sizes(1, self.config.patch_size, self.config.patch_size, False)[0]
+            if self._shadow is None or self._shadow.device != dev or self._shadow.numel() < nbytes:
+                self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            st = lib.sgl_prepare_weights(self._ctx, C.byref(self._weights_struct), self._shadow.data_ptr(),
+                                         self._shadow.numel(), _lib.current_stream_handle())
+            _lib.check(st, "sgl_prepare_weights", self._ctx)
+            self._shadow_key = key
+        return self._shadow, self._weights_struct
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._shadow = None
+        self._shadow_key = None
+        self._weights_struct = None
+        return out
+
+    def __del__(self):
+        try:
+            if self._ctx is not None and _lib._lib is not None:
+                _lib._lib.sgl_destroy(self._ctx)
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+# surface O
+# ---------------------------------------------------------------------------------------------------------
+class OpenClipStyleEncoder(nn.Module):
+    """``open_clip`` image-tower surface: ``encode_image(x)`` returns the attention-pooled, un-normalised
+    embedding (callers L2-normalise themselves: ``cifake_binary_classifier.py:728``)."""
+
+    def __init__(self, config, compute_dtype: str = "bf16"):
+        super().__init__()
+        self.visual = SiglipVisionModelHIP(config, compute_dtype)
+        self.embed_dim = self.visual.config.hidden_size
+        self.image_size = self.visual.config.image_size
+
+    def encode_image(self, x, normalize: bool = False):
+        out = self.visual(pixel_values=x, interpolate_pos_encoding=False)
+        f = out.pooler_output
+        if normalize:
+            f = f / f.norm(dim=-1, keepdim=True)
+        return f
+
+    def forward(self, image):
+        return self.encode_image(image)
+
+
+def _preprocess_factory(image_size: int):
+    """Resize(bilinear) + Normalize(0.5, 0.5) on an already-decoded float tensor in [0,1] (C,H,W)."""
+    def preprocess(img: torch.Tensor) -> torch.Tensor:
+        x = img.unsqueeze(0) if img.dim() == 3 else img
+        if x.shape[-1] != image_size or x.shape[-2] != image_size:
+            x = torch.nn.functional.interpolate(x, size=(image_size, image_size), mode="bilinear", align_corners=False)
+        x = (x - 0.5) / 0.5
+        return x[0] if img.dim() == 3 else x
+    return preprocess
+
+
+def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, device="cuda",
+                                compute_dtype: str = "bf16", seed: int = 0):
+    """Signature of ``open_clip.create_model_and_transforms`` as the reference calls it
+    (``cifake_binary_classifier.py:625-629``).  ``pretrained`` may be a local checkpoint directory; the
+    reference's ``'webli'`` tag needs the network, so it (like ``None``) selects seeded random init."""
+    cfg = get_config(model_name)
+    model = OpenClipStyleEncoder(cfg, compute_dtype)
+    if pretrained and os.path.isdir(pretrained):
+        from safetensors.torch import load_file
+        model.visual.load_state_dict(load_file(os.path.join(pretrained, "model.safetensors")))
+    else:
+        model.visual.load_state_dict(seeded_state_dict(cfg, seed))
+    model = model.to(device)
+    pre = _preprocess_factory(cfg.image_size)
+    return model, pre, pre

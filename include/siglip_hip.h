@@ -1,0 +1,181 @@
+/* siglip_hip.h — C ABI of libsiglip_hip.so: the MI355X (gfx950) SigLIP-2 vision-encoder hot path.
+ *
+ * The reference has no FFI of its own: its "plugin API" for this path is two Python call surfaces on an
+ * nn.Module obtained from third-party libraries:
+ *   surface H  self.encoder(pixel_values=..., output_hidden_states=True, interpolate_pos_encoding=True)
+ *              -> .pooler_output / .last_hidden_state / .hidden_states        Siglip2sidafrozen.py:753,787-793
+ *   surface O  backbone.encode_image(x) -> (B, D)                             cifake_binary_classifier.py:721,
+ *                                                                             hidf_video_classifier.py:307
+ * The entry points below are what a binding for that path binds instead of the HuggingFace / open_clip ViT:
+ * plain pointers and sizes, caller-owned memory, the caller's HIP stream.  INTEGRATION.md shows the ctypes
+ * stub.  Rules common to every call:
+ *   - returns 0 (SGL_OK) or a negative sgl_status; never throws, aborts, prints, allocates device memory or
+ *     synchronises the device; sgl_last_hip_error(ctx) holds the hipError_t behind SGL_ERR_HIP;
+ *   - all pointers are device pointers on the current device unless stated; work is enqueued on `stream`;
+ *   - re-entrant per ctx as long as the calls on one ctx are stream-ordered; no thread-local state (PyTorch runs
+ *     backward on an autograd worker thread);
+ *   - fp32 master parameters use the HuggingFace layouts (Linear W[out,in] row-major, patch conv W[D,3,p,p],
+ *     nn.MultiheadAttention in_proj_weight [3D,D] in q,k,v order).
+ */
+#ifndef SIGLIP_HIP_H
+#define SIGLIP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgl_ctx sgl_ctx;
+typedef void* sgl_stream; /* hipStream_t */
+
+enum { SGL_DTYPE_F32 = 0, SGL_DTYPE_BF16 = 1 };
+
+typedef enum {
+  SGL_OK = 0,
+  SGL_ERR_BAD_SHAPE = -1,   /* image not divisible into patches, non-square grid, dims not supported */
+  SGL_ERR_UNSUPPORTED = -2, /* dtype / config outside what the kernels implement */
+  SGL_ERR_WORKSPACE = -3,   /* saved / workspace / shadow buffer smaller than sgl_query_sizes reports */
+  SGL_ERR_HIP = -4,         /* a HIP call failed: see sgl_last_hip_error */
+  SGL_ERR_NULL = -5         /* a required pointer is NULL */
+} sgl_status;
+
+/* Immutable model description (HF SiglipVisionConfig fields; TF:models/siglip/configuration_siglip.py:90-99). */
+typedef struct {
+  int hidden_size;        /* D */
+  int intermediate_size;  /* I */
+  int num_layers;         /* L */
+  int num_heads;          /* H, head_dim = D / H must be a multiple of 8 and <= 96 */
+  int patch_size;         /* p */
+  int native_grid;        /* image_size / p : side of the stored position table */
+  float layer_norm_eps;   /* 1e-6 */
+  int compute_dtype;      /* SGL_DTYPE_BF16: bf16 MFMA operands, fp32 accumulate / residual stream / statistics;
+                             SGL_DTYPE_F32 : strict fp32 everywhere (parity mode) */
+  int use_head;           /* attention-pool head present (vision_use_head) */
+} sgl_config;
+
+/* fp32 master parameters of one encoder block (TF:modeling_siglip.py:268-271,315-316,329-331). */
+typedef struct {
+  const float *ln1_w, *ln1_b;
+  const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b;
+  const float *ln2_w, *ln2_b;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} sgl_layer_weights;
+
+typedef struct {
+  const float *patch_w, *patch_b; /* [D, 3*p*p], [D] */
+  const float* pos;               /* [native_grid^2, D] */
+  const sgl_layer_weights* layers; /* HOST array of num_layers entries (device pointers inside) */
+  const float *post_ln_w, *post_ln_b;
+  /* attention-pool head (TF:modeling_siglip.py:622-643); ignored when use_head == 0 */
+  const float *probe;                     /* [D] */
+  const float *in_proj_w, *in_proj_b;     /* [3D, D], [3D] */
+  const float *out_proj_w, *out_proj_b;   /* [D, D], [D] */
+  const float *head_ln_w, *head_ln_b;
+  const float *head_fc1_w, *head_fc1_b, *head_fc2_w, *head_fc2_b;
+} sgl_weights;
+
+/* Gradient destinations, same layouts as sgl_weights.  A NULL pointer means "frozen: do not compute".
+ * accumulate != 0 adds into the buffers (gradient accumulation), otherwise they are overwritten. */
+typedef struct {
+  float *ln1_w, *ln1_b;
+  float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b;
+  float *ln2_w, *ln2_b;
+  float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} sgl_layer_grads;
+
+typedef struct {
+  float *patch_w, *patch_b, *pos;
+  const sgl_layer_grads* layers; /* HOST array of num_layers entries */
+  float *post_ln_w, *post_ln_b;
+  float *probe, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *head_ln_w, *head_ln_b;
+  float *head_fc1_w, *head_fc1_b, *head_fc2_w, *head_fc2_b;
+  int accumulate;
+} sgl_grads;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+sgl_ctx* sgl_create(const sgl_config* cfg); /* NULL if the config is unsupported */
+void sgl_destroy(sgl_ctx* ctx);
+int sgl_last_hip_error(const sgl_ctx* ctx);
+const char* sgl_status_string(int status);
+int sgl_abi_version(void);
+
+/* ---- sizes (bytes) for caller-allocated buffers ----------------------------------------------------- */
+/* shadow: compute-dtype copies of the weight matrices (padded, plus pre-transposed forms for dX GEMMs);
+ * saved:  activations kept from forward for backward (0 when train == 0);
+ * ws:     scratch; must stay untouched between sgl_backward_begin and the last sgl_backward_* call. */
+int sgl_query_sizes(const sgl_ctx* ctx, int B, int H, int W, int train, size_t* shadow_bytes, size_t* saved_bytes,
+                    size_t* ws_bytes);
+
+/* Refresh the shadow arena from the fp32 masters (call after every optimizer step / load_state_dict).
+ * Replaces the per-step autocast weight casts of the reference (Siglip2sidafrozen.py:1375). */
+int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes, sgl_stream stream);
+
+/* ---- forward ---------------------------------------------------------------------------------------- */
+/* pixels: fp32 (B,3,H,W) NCHW, or NHWC storage when channels_last != 0 (reference .to(channels_last),
+ *         Siglip2sidafrozen.py:1191,1365).  Grid = (H / p, W / p) as in a "valid" conv (384 / 14 = 27).
+ * hidden_states: fp32 [hs_slots][B*N][D]; slot l holds hidden_states[l] of the HF output (0 = embeddings,
+ *         L = last block output before post_layernorm).  hs_slots = L+1 keeps all of them (required when
+ *         saved != NULL); hs_slots = 2 ping-pongs (inference without taps).
+ * last_hidden: fp32 [B*N][D] (post_layernorm output).   pooled: fp32 [B][D] or NULL.
+ * interpolate_pos != 0: bicubic-resize the position table when the grid differs from native
+ *         (TF:modeling_siglip.py:137-173); with 0 the grid must equal the native grid. */
+int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
+                int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
+                float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+
+/* ---- backward (stepwise so that a data-parallel caller can all-reduce each block's gradients while the
+ *      next block's backward runs; sgl_backward is the plain loop over the three steps) ------------------ */
+/* d_last_hidden [B*N][D], d_pooled [B][D], d_tap_last [B*N][D] (gradient w.r.t. hidden_states[L]); any may be
+ * NULL.  Computes head + post_layernorm gradients and leaves d hidden_states[L] in the workspace. */
+int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                       const float* hidden_states, const float* d_last_hidden, const float* d_pooled,
+                       const float* d_tap_last, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                       sgl_stream stream);
+/* Block `layer`: parameter gradients of that block, then workspace gradient := d hidden_states[layer]
+ * (+ d_tap, the external gradient w.r.t. hidden_states[layer], may be NULL).  need_dx == 0 skips the input
+ * gradient (first trainable block of a frozen prefix, Siglip2sidafrozen.py:762-768). */
+int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
+                       int H, int W, const float* hidden_states, const float* d_tap, int need_dx, const void* saved,
+                       size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+/* Patch-embedding / position-table gradients from the workspace gradient (d hidden_states[0]). */
+int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, int B, int H, int W, int interpolate_pos,
+                       const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+/* d_taps: HOST array of L+1 device pointers (NULL entries allowed) or NULL.  Stops above first_trainable_block. */
+int sgl_backward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                 int interpolate_pos, const float* hidden_states, const float* const* d_taps,
+                 const float* d_last_hidden, const float* d_pooled, int first_trainable_block, int train_embeddings,
+                 const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+
+/* ---- single-kernel entry points (unit parity tests, micro-benchmarks, roofline measurement) ----------- */
+int sgl_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                         float* rstd, int M, int D, float eps, sgl_stream stream);
+int sgl_op_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* dres, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                         float* dbeta, float* scratch, size_t scratch_bytes, int M, int D, sgl_stream stream);
+/* epilogue selectors for sgl_op_gemm_nt */
+enum { SGL_EPI_STORE = 0, SGL_EPI_BIAS_GELU = 1, SGL_EPI_RES_F32 = 2, SGL_EPI_QKV = 3, SGL_EPI_GELU_BWD = 4,
+       SGL_EPI_POS_F32 = 5, SGL_EPI_F32 = 6 };
+/* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue; dtype is the operand dtype (bf16 -> MFMA kernel). */
+int sgl_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* out,
+                   int ldo, void* out2, int ldo2, const float* bias, const float* res, int ldr, const void* aux,
+                   int ldaux, const float* pos, int pos_rows, int tokens, int heads, int head_dim, int head_dim_pad,
+                   int batch, sgl_stream stream);
+/* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 output). */
+int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
+                   float* out, int ldo, int accumulate, sgl_stream stream);
+int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
+                    int head_dim, int head_dim_pad, sgl_stream stream);
+int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                    const float* lse, void* dqkv, float* delta_scratch, int B, int H, int N, int head_dim,
+                    int head_dim_pad, sgl_stream stream);
+int sgl_op_colsum(int dtype, const void* in, int ld, int M, int N, float* out, int accumulate, float* scratch,
+                  size_t scratch_bytes, sgl_stream stream);
+int sgl_op_im2col(const float* pixels, int channels_last, void* out, int out_dtype, int B, int H, int W, int P, int Kp,
+                  sgl_stream stream);
+int sgl_op_pos_resize(const float* table, int native_grid, float* out, int gh, int gw, int D, sgl_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGLIP_HIP_H */
