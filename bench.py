@@ -1,0 +1,218 @@
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one training forward + backward of the SigLIP-2 so400m-patch14-384 vision encoder (+ pooling head)
+on one synthetic batch per GPU that is already resident in HBM: bf16 MFMA operands, fp32 accumulate / residual
+stream / master weights, the per-step refresh of the bf16 weight shadows (what autocast re-does every step in the
+reference, Siglip2sidafrozen.py:1375) and, for N > 1, the bucketed gradient all-reduce over RCCL overlapped with
+backward.  No optimizer step (metric is train fwd+bwd).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+PEAK_BF16_DENSE = 2.5e15   # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="so400m-patch14-384")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=0, help="image side (default: the config's native size)")
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--kernel-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
+    """Time the dominant kernel (the bf16 MFMA NT GEMM at the encoder's own shapes) with HIP events on the
+    stream it is launched on, and convert to achieved TFLOP/s.  One launch per shape per rep; the figure is
+    algorithmic FLOPs (2*M*N*K of the un-padded problem) / mean launch duration."""
+    import ctypes as C
+    lib = pkg.lib.load()
+    gh = res // cfg.patch_size
+    M = batch * gh * gh
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    Ip = (I + 127) // 128 * 128
+    dev = "cuda"
+    stream = torch.cuda.current_stream()
+    shapes = [  # (name, N, K, epi, N_alg, K_alg)
+        ("qkv", 3 * D, D, 3, 3 * D, D), ("out_proj", D, D, 2, D, D), ("fc1", Ip, D, 1, I, D), ("fc2", D, Ip, 2, D, I),
+    ]
+    per = {}
+    tot_t, tot_f = 0.0, 0.0
+    for name, N, K, epi, Na, Ka in shapes:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        Bw = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+        bias = torch.randn(N, device=dev)
+        res_t = torch.randn(M, N, device=dev) if epi == 2 else None
+        hd, H = cfg.head_dim, cfg.num_attention_heads
+        hdp = (hd + 15) // 16 * 16
+        if epi == 3:
+            out = torch.empty(3 * batch * H * gh * gh * hdp, device=dev, dtype=torch.bfloat16)
+        elif epi == 2:
+            out = torch.empty(M, N, device=dev)
+        else:
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == 1 else None
+
+        def launch():
+            st = lib.sgl_op_gemm_nt(1, A.data_ptr(), K, Bw.data_ptr(), K, M, N, K, epi, out.data_ptr(), N,
+                                    None if out2 is None else out2.data_ptr(), N, bias.data_ptr(),
+                                    None if res_t is None else res_t.data_ptr(), N, None, 0, None, 1, gh * gh, H, hd,
+                                    hdp, batch, stream.cuda_stream)
+            assert st == 0, st
+        launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        fl = 2.0 * M * Na * Ka
+        per[name] = {"ms": round(t * 1e3, 4), "tflops": round(fl / t / 1e12, 1)}
+        tot_t += t
+        tot_f += fl
+        del A, Bw, out, out2, res_t
+    achieved = tot_f / tot_t / 1e12
+    return {"bound": "mfma", "kernel": "sgl::gemm_nt_kernel (bf16 MFMA NT GEMM, fwd shapes of one block)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
+            "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None, "per_shape": per}
+
+
+def cpu_baseline(pkg, cfg, res, steps):
+    """The CPU oracle (port of the HF path, validated against HF in tests/) timed on this box's host cores."""
+    oracle = entry.load_oracle()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    B = 2
+    sd = {k: v.clone().requires_grad_(True) for k, v in pkg.weights.seeded_state_dict(cfg, seed=0).items()}
+    x = pkg.weights.seeded_pixels(B, res, res, seed=1234)
+
+    def step():
+        out = oracle.vision_forward(x, sd, cfg, False, True)
+        out["pooler_output"].square().mean().backward()
+        for v in sd.values():
+            v.grad = None
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{cfg_name_of(cfg)} fp32 oracle, batch {B}, {steps} timed fwd+bwd steps after 1 warm-up"}
+
+
+def cfg_name_of(cfg):
+    return f"D{cfg.hidden_size}-I{cfg.intermediate_size}-L{cfg.num_hidden_layers}-p{cfg.patch_size}@{cfg.image_size}"
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pkg = entry.load_package()
+    pkg.lib.load()
+    cfg = pkg.get_config(args.config)
+    res = args.res or cfg.image_size
+    dev = torch.device("cuda", local)
+
+    model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=args.mode)
+    model.load_state_dict(pkg.weights.seeded_state_dict(cfg, seed=0))
+    model = model.to(dev)
+    if world > 1:
+        pkg.ddp.broadcast_parameters(model, src=0)
+        pkg.GradBucketReducer().attach(model)
+    x = pkg.weights.seeded_pixels(args.batch, res, res, seed=1234 + rank).to(dev)
+    params = [p for p in model.parameters()]
+
+    def step():
+        model._shadow_key = None  # weights "changed" (optimizer step) -> refresh bf16 shadows, as autocast would
+        out = model(pixel_values=x, interpolate_pos_encoding=True)
+        loss = out.pooler_output.square().mean()
+        loss.backward()
+        for p in params:
+            p.grad = None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = dt / args.steps * 1e3
+    images = args.batch * world * args.steps
+    value = images / dt
+    gh = res // cfg.patch_size
+    train_flops = cfg.train_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
+
+    line = {
+        "metric": "images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.mode, "data": "synthetic",
+        "config": {"workload": f"{args.config} encoder+pool-head train fwd+bwd, {res}x{res}, per-GPU batch "
+                               f"{args.batch}, seeded random weights", "global_batch": args.batch * world,
+                   "tokens_per_image": gh * gh, "parallelism": f"dp{world}"},
+        "step_mfma_frac": round(value / world * train_flops / PEAK_BF16_DENSE, 4),
+        "train_tflop_per_image": round(train_flops / 1e12, 4),
+    }
+    if rank == 0:
+        if world == 1:
+            line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
+            del model
+            torch.cuda.empty_cache()
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(pkg, cfg, res, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

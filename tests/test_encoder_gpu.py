@@ -49,7 +49,14 @@ def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
         if k.startswith("grad.") and k.endswith(".shape"):
             name = k[len("grad."):-len(".shape")]
             assert sd[name].grad is not None, name
-            errs["g:" + name] = gu.compare(rec, "grad." + name, sd[name].grad.detach().cpu(), gatol + 1e-7, grtol)
+            a_tol = gatol + 1e-7
+            if name.endswith("k_proj.bias"):
+                # softmax is invariant to a per-query constant, so d k_proj.bias == 0 exactly in real arithmetic;
+                # what is left is rounding noise of sum_tokens(dK), bounded relative to the d q_proj.weight scale
+                a_tol = grtol * float(abs(rec["grad.encoder.layers.0.self_attn.q_proj.weight.full"]).max()
+                                      if "grad.encoder.layers.0.self_attn.q_proj.weight.full" in rec else
+                                      abs(rec["grad.encoder.layers.0.self_attn.q_proj.weight.samples"]).max())
+            errs["g:" + name] = gu.compare(rec, "grad." + name, sd[name].grad.detach().cpu(), a_tol, grtol)
             n += 1
     assert n >= 20
     worst = max(errs.items(), key=lambda kv: kv[1][0] / (kv[1][1] + 1e-9))
