@@ -692,10 +692,15 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   {
     float* gw[3] = {lg.q_w, lg.k_w, lg.v_w};
     float* gb[3] = {lg.q_b, lg.k_b, lg.v_b};
+    // when the caller laid the three gradients out back to back (the Python host does), q/k/v are one GEMM
+    const bool w_adj = gw[0] && gw[1] == gw[0] + (size_t)D * D && gw[2] == gw[1] + (size_t)D * D;
+    const bool b_adj = gb[0] && gb[1] == gb[0] + D && gb[2] == gb[1] + D;
+    if (w_adj) CK(gemm_tn(ctx, dqkv, 3 * D, lb + lay.r_h1, D, M, 3 * D, D, gw[0], D, acc, s));
+    if (b_adj) RET(bias_grad(ctx, lay, ws, dqkv, 3 * D, M, 3 * D, 3 * D, gb[0], acc, s));
     for (int j = 0; j < 3; ++j) {
       const char* aj = reinterpret_cast<const char*>(dqkv) + (size_t)j * D * ctx->es;
-      if (gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s));
-      RET(bias_grad(ctx, lay, ws, aj, 3 * D, M, D, D, gb[j], acc, s));
+      if (!w_adj && gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s));
+      if (!b_adj) RET(bias_grad(ctx, lay, ws, aj, 3 * D, M, D, D, gb[j], acc, s));
     }
   }
   if (d_tap) CK(add_f32(dx, d_tap, dx, (size_t)M * D, s));

@@ -49,15 +49,38 @@ __device__ __forceinline__ void store_tile(char* smem, f32x4 (&acc)[4][4], int w
       for (int r = 0; r < 4; ++r)
         ct[(wr * 64 + i * 16 + g * 4 + r) * G_CT_LD + wc * 64 + j * 16 + c16] = acc[i][j][r];
   __syncthreads();
+  if constexpr (EPI == EPI_F32) {
+    if (p.atomic) {
+      // split-K: fp32 atomics shaped as 256 contiguous bytes per wave instruction (one dword per lane)
+      float* outp = reinterpret_cast<float*>(p.out);
+      const int w = t >> 6;
+#pragma unroll 4
+      for (int rr = 0; rr < 32; ++rr) {
+        const int row = w + rr * 4;
+        const int grow = m0 + row;
+        if (grow >= M) continue;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+        for (int h = 0; h < 2; ++h) {
+          const int col = lane + 64 * h;
+          if (n0 + col < N) atomicAdd(outp + (size_t)grow * p.ldo + n0 + col, ct[row * G_CT_LD + col] * p.alpha);
+        }
+      }
+      return;
+    }
+  }
+  // fp32 outputs: 4 columns (16 B) per lane so a wave instruction covers two whole 512-B rows;
+  // bf16 outputs: 8 columns (16 B) per lane, four 256-B rows per wave instruction
+  constexpr int NV = (sizeof(TOut) == 4) ? 4 : 8;
+  constexpr int CPR = G_BN / NV;
+#pragma unroll
+  for (int q = 0; q < (G_BM * CPR) / 256; ++q) {
     const int c = t + q * 256;
-    const int row = c >> 4, col = (c & 15) * 8;
+    const int row = c / CPR, col = (c % CPR) * NV;
     const int grow = m0 + row, gcol = n0 + col;
     if (grow < M && gcol < N) {
-      float v[8];
-      Vec<float, 8>::ld(ct + row * G_CT_LD + col, v);
-      epi_apply<EPI, TOut, 8>(p, grow, gcol, N, v);
+      float v[NV];
+      Vec<float, NV>::ld(ct + row * G_CT_LD + col, v);
+      epi_apply<EPI, TOut, NV>(p, grow, gcol, N, v);
     }
   }
 }

@@ -8,9 +8,9 @@
 
 namespace sgl {
 
-constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+constexpr int LN_MAXV_MAX = 8;  // float4 per lane -> D <= 2048 (instantiated for 2, 5, 8 to keep occupancy)
 
-template <typename TOut>
+template <typename TOut, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TOut* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
@@ -63,22 +63,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+template <typename TOut>
+static hipError_t ln_fwd_launch(const float* x, const float* gamma, const float* beta, TOut* y, int ldy, float* mean,
+                                float* rstd, int M, int D, float eps, hipStream_t s) {
+  dim3 grid((M + 3) / 4), block(256);
+  if (D <= 512)
+    hipLaunchKernelGGL((ln_fwd_kernel<TOut, 2>), grid, block, 0, s, x, gamma, beta, y, ldy, mean, rstd, M, D, eps);
+  else if (D <= 1280)
+    hipLaunchKernelGGL((ln_fwd_kernel<TOut, 5>), grid, block, 0, s, x, gamma, beta, y, ldy, mean, rstd, M, D, eps);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<TOut, 8>), grid, block, 0, s, x, gamma, beta, y, ldy, mean, rstd, M, D, eps);
+  return hipGetLastError();
+}
+
 hipError_t layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, int ldy,
                          float* mean, float* rstd, int M, int D, float eps, hipStream_t s) {
-  if (D % 4 || D > 64 * 4 * LN_MAXV || ldy % 4) return hipErrorInvalidValue;
+  if (D % 4 || D > 64 * 4 * LN_MAXV_MAX || ldy % 4) return hipErrorInvalidValue;
   if (M == 0) return hipSuccess;
-  dim3 grid((M + 3) / 4), block(256);
-  if (y_dtype == DT_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, s, x, gamma, beta, (bf16*)y, ldy, mean, rstd, M, D, eps);
-  else
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, x, gamma, beta, (float*)y, ldy, mean, rstd, M, D, eps);
-  return hipGetLastError();
+  if (y_dtype == DT_BF16) return ln_fwd_launch<bf16>(x, gamma, beta, (bf16*)y, ldy, mean, rstd, M, D, eps, s);
+  return ln_fwd_launch<float>(x, gamma, beta, (float*)y, ldy, mean, rstd, M, D, eps, s);
 }
 
 // Backward.  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  optional "+ dres" fuses the
 // residual-branch gradient; optional low-precision copy of dx feeds the next backward GEMM's A operand.
 // dgamma/dbeta: per-lane register partials over the block's rows -> LDS -> partial[block][2D].
-template <typename TDy, typename TLp>
+template <typename TDy, typename TLp, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
@@ -161,53 +170,76 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 
 int layernorm_bwd_blocks(int M) {
   int b = (M + 3) / 4;
-  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  return b < 1 ? 1 : (b > 512 ? 512 : b);
+}
+
+template <typename TDy, typename TLp>
+static hipError_t ln_bwd_launch2(const void* dy, int lddy, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dres, float* dx, void* dx_lp, float* partial,
+                                 int nblk, int M, int D, hipStream_t s) {
+  dim3 grid(nblk), block(256);
+  const size_t smem = (size_t)4 * 2 * D * sizeof(float);
+#define SGL_LNB(V)                                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDy, TLp, V>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma, \
+                     dres, dx, (TLp*)dx_lp, partial, M, D)
+  if (D <= 512)
+    SGL_LNB(2);
+  else if (D <= 1280)
+    SGL_LNB(5);
+  else
+    SGL_LNB(8);
+#undef SGL_LNB
+  return hipGetLastError();
 }
 
 template <typename TDy>
 static hipError_t ln_bwd_launch(const void* dy, int lddy, const float* x, const float* mean, const float* rstd,
                                 const float* gamma, const float* dres, float* dx, void* dx_lp, int lp_dtype,
                                 float* partial, int nblk, int M, int D, hipStream_t s) {
-  dim3 grid(nblk), block(256);
-  size_t smem = (size_t)4 * 2 * D * sizeof(float);
   if (lp_dtype == DT_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<TDy, bf16>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma,
-                       dres, dx, (bf16*)dx_lp, partial, M, D);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<TDy, float>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma,
-                       dres, dx, (float*)dx_lp, partial, M, D);
-  return hipGetLastError();
+    return ln_bwd_launch2<TDy, bf16>(dy, lddy, x, mean, rstd, gamma, dres, dx, dx_lp, partial, nblk, M, D, s);
+  return ln_bwd_launch2<TDy, float>(dy, lddy, x, mean, rstd, gamma, dres, dx, dx_lp, partial, nblk, M, D, s);
 }
 
 hipError_t layernorm_bwd(const void* dy, int dy_dtype, int lddy, const float* x, const float* mean,
                          const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_lp,
                          int lp_dtype, float* partial, int nblk, int M, int D, hipStream_t s) {
-  if (D % 4 || D > 64 * 4 * LN_MAXV || lddy % 4) return hipErrorInvalidValue;
+  if (D % 4 || D > 64 * 4 * LN_MAXV_MAX || lddy % 4) return hipErrorInvalidValue;
   if (M == 0) return hipSuccess;
   if (dy_dtype == DT_BF16)
     return ln_bwd_launch<bf16>(dy, lddy, x, mean, rstd, gamma, dres, dx, dx_lp, lp_dtype, partial, nblk, M, D, s);
   return ln_bwd_launch<float>(dy, lddy, x, mean, rstd, gamma, dres, dx, dx_lp, lp_dtype, partial, nblk, M, D, s);
 }
 
+// out[j] (+)= sum_b partial[b*stride + j]: 32 columns x 8 row-groups per block, LDS tree across the groups
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int stride,
                                                               float* __restrict__ out, int n, int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float s0 = 0.f, s1 = 0.f;
-  int b = 0;
-  for (; b + 1 < nblk; b += 2) {
-    s0 += partial[(size_t)b * stride + j];
-    s1 += partial[(size_t)(b + 1) * stride + j];
+  if (j < n) {
+    int b = g;
+    for (; b + 8 < nblk; b += 16) {
+      s0 += partial[(size_t)b * stride + j];
+      s1 += partial[(size_t)(b + 8) * stride + j];
+    }
+    if (b < nblk) s0 += partial[(size_t)b * stride + j];
   }
-  if (b < nblk) s0 += partial[(size_t)b * stride + j];
-  const float r = s0 + s1;
-  out[j] = accumulate ? out[j] + r : r;
+  red[g][c] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][c];
+    out[j] = accumulate ? out[j] + r : r;
+  }
 }
 
 hipError_t reduce_partials(const float* partial, int nblk, int stride, float* out, int n, int accumulate,
                            hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, nblk, stride, out, n,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, nblk, stride, out, n,
                      accumulate);
   return hipGetLastError();
 }

@@ -199,14 +199,17 @@ class _EncoderFn(torch.autograd.Function):
             if needs[idx]:
                 groups.setdefault(grp, []).append(idx)
         buckets: dict[str, torch.Tensor] = {}
+        # q/k/v weight (and bias) gradients back to back: the C side then runs them as one dW GEMM / one column sum
+        rank = {"q_w": 0, "k_w": 1, "v_w": 2, "q_b": 3, "k_b": 4, "v_b": 5}
         for grp, idxs in groups.items():
-            total = sum(params[i].numel() for i in idxs)
-            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            idxs.sort(key=lambda i: (rank.get(names[i][1], 6), i))
+            total = sum((params[i].numel() + 3) // 4 * 4 for i in idxs)   # every tensor 16-byte aligned
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
             off = 0
             for i in idxs:
                 n = params[i].numel()
                 grads_out[i] = flat[off:off + n].view(params[i].shape)
-                off += n
+                off += (n + 3) // 4 * 4
             buckets[grp] = flat
 
         gl = (_lib.SglLayerPtrs * max(L, 1))()
