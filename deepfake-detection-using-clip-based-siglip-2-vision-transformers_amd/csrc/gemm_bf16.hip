@@ -19,6 +19,8 @@
 // residual, head-major QKV scatter, ...) works on 8 consecutive columns per lane with 16-byte global accesses.
 //
 // Roofline: MFMA-bound (arithmetic intensity K/2... >> machine balance); algorithmic FLOPs = 2*M*N*K.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "epilogue.cuh"
 #include "kernels.h"
@@ -284,6 +286,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16* __restrict_
 // ------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------
+// 256x256-tile LDS-DMA generation (gemm_bf16_v2.hip); used whenever the problem is large enough to fill the chip
+hipError_t gemm_nt2_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, int out_dtype,
+                         const EpiParams& p, hipStream_t s);
+hipError_t gemm_tn2_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int m_per,
+                         int splits, const EpiParams& p, hipStream_t s);
+static int gemm_generation() {  // SGL_GEMM_GEN=1 forces the 128x128 register-staged kernels (A/B comparisons)
+  static int gen = -1;
+  if (gen < 0) {
+    const char* e = getenv("SGL_GEMM_GEN");
+    gen = (e && e[0] == '1') ? 1 : 2;
+  }
+  return gen;
+}
 static bool g_attr_done = false;
 
 template <int EPI, typename TOut>
@@ -307,6 +322,7 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if ((lda % 8) || (ldb % 8) || (K % 8) || K <= 0) return hipErrorInvalidValue;
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+ if (gemm_generation() == 2 && M >= 2048 && N >= 256) return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
   const bf16* A = (const bf16*)A_;
   const bf16* B = (const bf16*)B_;
 #define SGL_CASE(E)                                                                   \
@@ -343,6 +359,26 @@ hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mr
     if (!p.accumulate)
       return hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
     return hipSuccess;
+  }
+  if (gemm_generation() == 2 && N1 >= 512 && N2 >= 512 && Mred >= 2048) {
+    // 256x256 tiles, one workgroup per CU: split the token reduction until ~256 workgroups exist
+    const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);
+    // one workgroup per CU (128 KiB LDS): keep tiles*splits <= 256 so the grid is a single full round
+    int sp = 256 / tiles;
+    if (sp < 1) sp = 1;
+    const int max_sp = Mred / 1024 > 0 ? Mred / 1024 : 1;
+    if (sp > max_sp) sp = max_sp;
+    int mp = (Mred + sp - 1) / sp;
+    mp = ((mp + G_BK - 1) / G_BK) * G_BK;
+    sp = (Mred + mp - 1) / mp;
+    if (sp > 1) {
+      if (!p.accumulate) {
+        hipError_t e = hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
+        if (e != hipSuccess) return e;
+      }
+      p.atomic = 1;
+    }
+    return gemm_tn2_bf16(A_, lda, B_, ldb, Mred, N1, N2, mp, sp, p, s);
   }
   if (splits < 1) splits = 1;
   int m_per = (Mred + splits - 1) / splits;

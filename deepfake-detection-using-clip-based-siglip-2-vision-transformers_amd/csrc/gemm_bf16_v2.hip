@@ -1,0 +1,339 @@
+// Second-generation bf16 MFMA GEMMs for gfx950: 256x256 output tile, K-step 64, 512 threads = 8 waves, operands
+// streamed global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no VGPR staging),
+// two LDS stages (2 x 64 KiB), one barrier per K-step: the DMA for step t+1 is issued right after the barrier
+// that retires step t's DMA and runs under step t's 64 MFMAs per wave.
+//
+//   nt2 : C[M,N]   = A[M,K] · B[N,K]ᵀ           (forward projections, dX with transposed weight shadows)
+//   tn2 : C[N1,N2] (+)= Σ_m A[m,N1] · B[m,N2]    (dW; token index is the MFMA k index via ds_read_b64_tr_b16)
+//
+// Arithmetic intensity of the tile: 2*256*256*64 / (2*256*64*2 B) = 128 FLOP per LDS-staged byte (the 128x128
+// tile of gemm_bf16.hip has 64 and is L2->LDS bandwidth bound near 0.6-0.7 PFLOP/s on this chip).
+//
+// LDS-DMA writes lane-linear (wave-uniform base + lane*16), so the bank-conflict swizzles are applied to each
+// lane's SOURCE address and again on the fragment reads (same involution on both sides):
+//   nt2 image [256 rows][64 k]   128-B rows: slot s of row r holds source chunk s ^ (r & 7)
+//   tn2 image [64 m][256 n]      512-B rows: slot s of row m holds source chunk s ^ (2*(m&3) + 8*((m>>3)&1))
+// Wave w -> (wr, wc) = ((w>>1)&1, (w&1) + 2*(w>>2)) so that the two waves sharing a SIMD (w, w+4) sit in different
+// column halves: a half-empty last column tile (N = 1152 = 4.5 tiles) then costs half a tile, not a whole one.
+// blockIdx -> tile is XCD-aware: the 8 XCDs (round-robin over blockIdx) each own the row panels tile_m ≡ xcd (mod 8),
+// so an A panel is fetched into one L2 only.  Placement affects speed only.
+#include "common.cuh"
+#include "epilogue.cuh"
+#include "kernels.h"
+
+namespace sgl {
+
+constexpr int T_BM = 256, T_BN = 256, T_BK = 64;
+constexpr int T_OP = T_BM * T_BK * 2;     // 32 KiB per operand per stage
+constexpr int T_STAGE = 2 * T_OP;         // 64 KiB
+constexpr int T_LDS = 2 * T_STAGE;        // 128 KiB
+constexpr int T_CT_LD = 260;              // fp32 epilogue staging stride (64 rows x 260 floats = 66,560 B)
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds, uint32_t voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (SGL_LDS void*)lds, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 lds_tr16v2(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SGL_LDS bf16x4*)(p));
+}
+
+// accumulators -> LDS (64 rows at a time) -> row-contiguous chunks -> fused epilogue
+template <int EPI, typename TOut>
+__device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], int wr, int wc, int lane, int t, int m0,
+                                              int n0, int M, int N, const EpiParams& p) {
+  float* ct = reinterpret_cast<float*>(smem);
+  const int g = lane >> 4, c16 = lane & 15;
+  constexpr int NV = (sizeof(TOut) == 4) ? 4 : 8;
+  constexpr int CPR = T_BN / NV;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    __syncthreads();
+    if (wr == (pass >> 1)) {
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ct[(i2 * 16 + g * 4 + r) * T_CT_LD + wc * 64 + j * 16 + c16] = acc[4 * (pass & 1) + i2][j][r];
+    }
+    __syncthreads();
+    const int mrow0 = m0 + pass * 64;
+    if constexpr (EPI == EPI_F32) {
+      if (p.atomic) {
+        float* outp = reinterpret_cast<float*>(p.out);
+        const int w = t >> 6;
+#pragma unroll 2
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = w + rr * 8;
+          const int grow = mrow0 + row;
+          if (grow >= M) continue;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int col = lane + 64 * h;
+            if (n0 + col < N) atomicAdd(outp + (size_t)grow * p.ldo + n0 + col, ct[row * T_CT_LD + col] * p.alpha);
+          }
+        }
+        continue;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < (64 * CPR) / 512; ++q) {
+      const int c = t + q * 512;
+      const int row = c / CPR, col = (c % CPR) * NV;
+      const int grow = mrow0 + row, gcol = n0 + col;
+      if (grow < M && gcol < N) {
+        float v[NV];
+        Vec<float, NV>::ld(ct + row * T_CT_LD + col, v);
+        epi_apply<EPI, TOut, NV>(p, grow, gcol, N, v);
+      }
+    }
+  }
+}
+
+// Compile-time interleave for one K-step: READS LDS reads per fragment (1 = ds_read_b128, 2 = two ds_read_b64_tr_b16).
+// prologue 7 fragments (4 B + 3 A), then 16 x {4 MFMA, prefetch of A[f+3] (+ one B fragment of the 2nd k-half at f=3..6)}
+template <int READS, int F>
+__device__ __forceinline__ void sched_step() {
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  if constexpr (F <= 12) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+  if constexpr (F >= 3 && F < 7) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+}
+template <int READS>
+__device__ __forceinline__ void sched_pipeline() {
+  __builtin_amdgcn_sched_group_barrier(0x100, 7 * READS, 0);
+  sched_step<READS, 0>();  sched_step<READS, 1>();  sched_step<READS, 2>();  sched_step<READS, 3>();
+  sched_step<READS, 4>();  sched_step<READS, 5>();  sched_step<READS, 6>();  sched_step<READS, 7>();
+  sched_step<READS, 8>();  sched_step<READS, 9>();  sched_step<READS, 10>(); sched_step<READS, 11>();
+  sched_step<READS, 12>(); sched_step<READS, 13>(); sched_step<READS, 14>(); sched_step<READS, 15>();
+}
+
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const int xcd = bid & 7, local = bid >> 3;
+  tile_n = local % tiles_n;
+  tile_m = (local / tiles_n) * 8 + xcd;
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int EPI, typename TOut>
+__global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict__ A, int lda,
+                                                          const bf16* __restrict__ B, int ldb, int M, int N, int K,
+                                                          int tiles_m, int tiles_n, EpiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n;
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
+  if (tile_m >= tiles_m) return;  // whole block exits together
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2);
+  const int m0 = tile_m * T_BM, n0 = tile_n * T_BN;
+  const int rows_a = (M - m0 < T_BM) ? M - m0 : T_BM;
+  const int rows_b = (N - n0 < T_BN) ? N - n0 : T_BN;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)m0 * lda, (uint32_t)(((size_t)(rows_a - 1) * lda + K) * 2));
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (size_t)n0 * ldb, (uint32_t)(((size_t)(rows_b - 1) * ldb + K) * 2));
+
+  // DMA assignment: wave w moves rows [w*32, w*32+32) of each operand, 8 rows (1 KiB) per instruction
+  const int drow = lane >> 3;
+  const int dchunk = (lane & 7) ^ drow;
+  uint32_t a_off[4], b_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = w * 32 + q * 8 + drow;
+    a_off[q] = (row < rows_a) ? (uint32_t)(row * lda + dchunk * 8) * 2u : SGL_OOB;
+    b_off[q] = (row < rows_b) ? (uint32_t)(row * ldb + dchunk * 8) * 2u : SGL_OOB;
+  }
+  auto issue = [&](int kt, int stage) {
+    const int k0 = kt * T_BK;
+    const bool kok = (k0 + dchunk * 8) < K;
+    char* base = smem + stage * T_STAGE + (w * 32) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dma16(ra, base + q * 1024, (kok && a_off[q] != SGL_OOB) ? a_off[q] + (uint32_t)k0 * 2u : SGL_OOB);
+      dma16(rb, base + T_OP + q * 1024, (kok && b_off[q] != SGL_OOB) ? b_off[q] + (uint32_t)k0 * 2u : SGL_OOB);
+    }
+  };
+
+  const int frow = lane & 15, fg = lane >> 4, fsw = frow & 7;
+  const uint32_t fa_base = (uint32_t)((wr * 128 + frow) * 128);
+  const uint32_t fb_base = (uint32_t)(T_OP + (wc * 64 + frow) * 128);
+  const bool active = (n0 + wc * 64 < N) && (m0 + wr * 128 < M);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + T_BK - 1) / T_BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // drains this wave's DMA (vmcnt(0)) and orders every wave past step kt-1
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (active) {
+      // 16 fragment steps per K-step: step f = (k-half f>>3, 16-row tile f&7) feeds 4 MFMAs.  A fragments are read
+      // three steps ahead, the second k-half's B fragments during steps 3..6, and sched_group_barrier pins the
+      // ds_read/MFMA interleave so the LDS latency hides under the MFMAs of the same wave.
+      const char* base = smem + (kt & 1) * T_STAGE;
+      const char* pa = base + fa_base;
+      const char* pb = base + fb_base;
+      const uint32_t c0 = (uint32_t)(((0 + fg) ^ fsw) << 4), c1 = (uint32_t)(((4 + fg) ^ fsw) << 4);
+      bf16x8 a[16], b[2][4];
+#define SGL_LDA(f) (*reinterpret_cast<const bf16x8*>(pa + ((f) & 7) * 2048 + (((f) >> 3) ? c1 : c0)))
+#define SGL_LDB(s_, j) (*reinterpret_cast<const bf16x8*>(pb + (j) * 2048 + ((s_) ? c1 : c0)))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[0][j] = SGL_LDB(0, j);
+      a[0] = SGL_LDA(0);
+      a[1] = SGL_LDA(1);
+      a[2] = SGL_LDA(2);
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        if (f + 3 < 16) a[f + 3] = SGL_LDA(f + 3);
+        if (f >= 3 && f < 7) b[1][f - 3] = SGL_LDB(1, f - 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[f & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b[f >> 3][j], acc[f & 7][j], 0, 0, 0);
+      }
+#undef SGL_LDA
+#undef SGL_LDB
+      sched_pipeline<1>();
+    }
+  }
+  store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict__ A, int lda,
+                                                          const bf16* __restrict__ B, int ldb, int Mred, int N1, int N2,
+                                                          int m_per_split, int tiles_1, int tiles_2, EpiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tile1 = blockIdx.x / tiles_2, tile2 = blockIdx.x - tile1 * tiles_2;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2);
+  const int n1_0 = tile1 * T_BM, n2_0 = tile2 * T_BN;
+  const int m_begin = blockIdx.y * m_per_split;
+  const int m_end = (m_begin + m_per_split < Mred) ? m_begin + m_per_split : Mred;
+  const int rows = m_end - m_begin;
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)m_begin * lda, (uint32_t)((size_t)rows * lda * 2));
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(B + (size_t)m_begin * ldb, (uint32_t)((size_t)rows * ldb * 2));
+
+  // DMA: image [64 m][256 n] with 512-B rows; wave w moves rows [w*8, w*8+8), 2 rows (1 KiB) per instruction
+  const int dr2 = lane >> 5, dslot = lane & 31;
+  uint32_t a_off[4], b_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = w * 8 + q * 2 + dr2;
+    const int chunk = dslot ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
+    const int ca = n1_0 + chunk * 8, cb = n2_0 + chunk * 8;
+    a_off[q] = (ca < N1) ? (uint32_t)(row * lda + ca) * 2u : SGL_OOB;
+    b_off[q] = (cb < N2) ? (uint32_t)(row * ldb + cb) * 2u : SGL_OOB;
+  }
+  auto issue = [&](int kt, int stage) {
+    const uint32_t r0 = (uint32_t)kt * T_BK;
+    char* base = smem + stage * T_STAGE + (w * 8) * 512;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dma16(ra, base + q * 1024, a_off[q] == SGL_OOB ? SGL_OOB : a_off[q] + r0 * (uint32_t)lda * 2u);
+      dma16(rb, base + T_OP + q * 1024, b_off[q] == SGL_OOB ? SGL_OOB : b_off[q] + r0 * (uint32_t)ldb * 2u);
+    }
+  };
+
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  const uint32_t swz = (uint32_t)(32 * fq + 128 * (fg & 1));
+  const uint32_t frow = (uint32_t)((8 * fg + fq) * 512);
+  const uint32_t fa_col = ((uint32_t)(wr * 256 + 8 * fp)) ^ swz;   // + i*32 bytes per 16-column tile (bits 5.. stay XOR-safe)
+  const uint32_t fb_col = ((uint32_t)(wc * 128 + 8 * fp)) ^ swz;
+  const bool active = (n2_0 + wc * 64 < N2) && (n1_0 + wr * 128 < N1);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (rows + T_BK - 1) / T_BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (active) {
+      // same 16-step pipeline as nt2; every fragment is two transposed 8-byte reads
+      const char* base = smem + (kt & 1) * T_STAGE + frow;
+      bf16x8 a[16], b[2][4];
+#define SGL_TR(ptr) __builtin_shufflevector(lds_tr16v2(ptr), lds_tr16v2((ptr) + 4 * 512), 0, 1, 2, 3, 4, 5, 6, 7)
+#define SGL_LDA(f) SGL_TR(base + ((f) >> 3) * 32 * 512 + (fa_col ^ (uint32_t)(((f) & 7) * 32)))
+#define SGL_LDB(s_, j) SGL_TR(base + T_OP + (s_) * 32 * 512 + (fb_col ^ (uint32_t)((j) * 32)))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[0][j] = SGL_LDB(0, j);
+      a[0] = SGL_LDA(0);
+      a[1] = SGL_LDA(1);
+      a[2] = SGL_LDA(2);
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        if (f + 3 < 16) a[f + 3] = SGL_LDA(f + 3);
+        if (f >= 3 && f < 7) b[1][f - 3] = SGL_LDB(1, f - 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[f & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b[f >> 3][j], acc[f & 7][j], 0, 0, 0);
+      }
+#undef SGL_LDA
+#undef SGL_LDB
+#undef SGL_TR
+      sched_pipeline<2>();
+    }
+  }
+  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int EPI, typename TOut>
+static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int M, int N, int K, const EpiParams& p,
+                             hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt2_kernel<EPI, TOut>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + T_BN - 1) / T_BN;
+  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
+                     tiles_n, p);
+  return hipGetLastError();
+}
+
+hipError_t gemm_nt2_bf16(const void* A_, int lda, const void* B_, int ldb, int M, int N, int K, int epi, int out_dtype,
+                         const EpiParams& p, hipStream_t s) {
+  const bf16* A = (const bf16*)A_;
+  const bf16* B = (const bf16*)B_;
+  switch (epi) {
+    case EPI_STORE:
+      return out_dtype == DT_BF16 ? launch_nt2<EPI_STORE, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt2<EPI_STORE, float>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_BIAS_GELU: return launch_nt2<EPI_BIAS_GELU, bf16>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_QKV: return launch_nt2<EPI_QKV, bf16>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_GELU_BWD: return launch_nt2<EPI_GELU_BWD, bf16>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_RES_F32: return launch_nt2<EPI_RES_F32, float>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_POS_F32: return launch_nt2<EPI_POS_F32, float>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_F32: return launch_nt2<EPI_F32, float>(A, lda, B, ldb, M, N, K, p, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t gemm_tn2_bf16(const void* A_, int lda, const void* B_, int ldb, int Mred, int N1, int N2, int m_per,
+                         int splits, const EpiParams& p, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int tiles_1 = (N1 + T_BM - 1) / T_BM, tiles_2 = (N2 + T_BN - 1) / T_BN;
+  const int grid = tiles_1 * tiles_2;
+  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid, splits), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_,
+                     ldb, Mred, N1, N2, m_per, tiles_1, tiles_2, p);
+  return hipGetLastError();
+}
+
+}  // namespace sgl

@@ -88,7 +88,9 @@ def call_gemm_nt(lib, dtype, A, B, M, N, K, epi, out, ldo, out2=None, ldo2=0, bi
 
 
 GEMM_SHAPES = [(128, 128, 64), (1, 8, 8), (200, 136, 72), (729, 1152, 1152), (1458, 3456, 1152), (300, 1152, 4352),
-               (64, 4352, 1152), (257, 144, 640)]
+               (64, 4352, 1152), (257, 144, 640),
+               # large enough for the 256x256-tile LDS-DMA generation (M >= 2048, N >= 256), with M/N/K tails
+               (4096, 1152, 1152), (2300, 4352, 1152), (2125, 1152, 4352), (2916, 3456, 1152), (2049, 264, 72)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -105,12 +107,12 @@ def test_gemm_nt_store_bias(lib, M, N, K, dtype):
     assert relerr(out, ref) < (6e-3 if dtype == BF16 else 2e-5)
 
 
-@pytest.mark.parametrize("dtype", [BF16, F32])
-def test_gemm_nt_epilogues(lib, dtype):
+@pytest.mark.parametrize("dtype,M", [(BF16, 333), (BF16, 2333), (F32, 333)])
+def test_gemm_nt_epilogues(lib, dtype, M):
     torch.manual_seed(5)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
     tol = 8e-3 if dtype == BF16 else 3e-5
-    M, N, K = 333, 256, 192
+    N, K = 384, 192
     A = torch.randn(M, K, device="cuda").to(tdt)
     B = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(tdt)
     bias = torch.randn(N, device="cuda")
@@ -146,7 +148,8 @@ def test_gemm_nt_epilogues(lib, dtype):
 
 
 @pytest.mark.parametrize("dtype", [BF16, F32])
-@pytest.mark.parametrize("batch,tokens,heads,hd", [(2, 9, 2, 72), (3, 49, 4, 16), (1, 729, 16, 72), (2, 196, 12, 64)])
+@pytest.mark.parametrize("batch,tokens,heads,hd", [(2, 9, 2, 72), (3, 49, 4, 16), (1, 729, 16, 72), (2, 196, 12, 64),
+                                                   (3, 729, 16, 72), (11, 196, 12, 64)])
 def test_gemm_nt_qkv_scatter(lib, dtype, batch, tokens, heads, hd):
     torch.manual_seed(11)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
@@ -167,7 +170,8 @@ def test_gemm_nt_qkv_scatter(lib, dtype, batch, tokens, heads, hd):
 
 @pytest.mark.parametrize("Mred,N1,N2,splits", [(64, 128, 128, 1), (729, 144, 144, 1), (1458, 1152, 1152, 4),
                                                  (2187, 538, 144, 3), (300, 256, 588, 1), (5000, 4304, 1152, 2),
-                                                 (130, 8, 16, 1)])
+                                                 (130, 8, 16, 1), (4100, 3456, 1152, 1), (2048, 1152, 1152, 1),
+                                                 (2916, 1152, 4304, 1), (2500, 538, 640, 1), (9000, 1152, 588, 1)])
 @pytest.mark.parametrize("dtype", [BF16, F32])
 def test_gemm_tn(lib, Mred, N1, N2, splits, dtype):
     torch.manual_seed(Mred + N1)
