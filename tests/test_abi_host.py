@@ -1,0 +1,127 @@
+"""CPU (no GPU): the C-ABI library builds, loads and exports every symbol include/siglip_hip.h declares; the ctypes
+binding matches the header's parameter counts; host-only entry points (create / query_sizes / status strings)
+behave; the Python host surface mirrors the reference's interface (state-dict keys, freezing, error behaviour).
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+
+def _prototypes(header_path):
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(sgl_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        protos[m.group(1)] = n
+    return protos
+
+
+def test_library_exports_every_declared_symbol(pkg, hiplib):
+    protos = _prototypes(pkg.lib.HEADER_PATH)
+    assert len(protos) >= 20
+    for name, nargs in protos.items():
+        fn = getattr(hiplib, name)  # raises AttributeError when the symbol is missing
+        assert fn.argtypes is not None, f"{name} has no ctypes signature"
+        assert len(fn.argtypes) == nargs, f"{name}: header has {nargs} parameters, binding {len(fn.argtypes)}"
+    assert set(pkg.lib.declared_symbols()) == set(protos)
+    assert hiplib.sgl_abi_version() == 1
+    assert hiplib.sgl_status_string(0) == b"ok" and hiplib.sgl_status_string(-3) == b"buffer too small"
+
+
+def test_create_and_query_sizes_host_logic(pkg, hiplib):
+    L = pkg.lib
+    good = L.SglConfig(1152, 4304, 27, 16, 14, 27, 1e-6, L.SGL_DTYPE_BF16, 1)
+    ctx = hiplib.sgl_create(C.byref(good))
+    assert ctx
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert hiplib.sgl_query_sizes(ctx, 64, 384, 384, 1, C.byref(a), C.byref(b), C.byref(c)) == 0
+    shadow64, saved64, ws64 = a.value, b.value, c.value
+    assert hiplib.sgl_query_sizes(ctx, 32, 384, 384, 1, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert a.value == shadow64 and b.value < saved64 and c.value < ws64
+    # bf16 shadows: 2 copies (plain + transposed) of every matrix, a bit above 2 * 2 bytes * matrix params
+    mats = 27 * (4 * 1152 * 1152 + 2 * 1152 * 4304)
+    assert 4 * mats < shadow64 < 4.4 * mats + (1 << 24)
+    # saved activations fit the 288 GB HBM3E budget with room to spare at the benchmark batch
+    assert saved64 < 60 * (1 << 30)
+    assert hiplib.sgl_query_sizes(ctx, 64, 384, 384, 0, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert b.value == 0 and c.value > 0
+    assert hiplib.sgl_query_sizes(ctx, 0, 384, 384, 1, None, None, None) == -1      # bad batch
+    assert hiplib.sgl_query_sizes(ctx, 2, 10, 384, 1, None, None, None) == -1       # smaller than a patch
+    assert hiplib.sgl_query_sizes(None, 2, 384, 384, 1, None, None, None) == -5
+    hiplib.sgl_destroy(ctx)
+    for bad in [L.SglConfig(1150, 4304, 27, 16, 14, 27, 1e-6, 1, 1),    # D not divisible by heads
+                L.SglConfig(1152, 4304, 27, 8, 14, 27, 1e-6, 1, 1),     # head_dim 144 > 96
+                L.SglConfig(1152, 4304, 27, 16, 14, 27, 1e-6, 7, 1),    # unknown dtype
+                L.SglConfig(1152, 0, 27, 16, 14, 27, 1e-6, 1, 1)]:
+        assert not hiplib.sgl_create(C.byref(bad))
+
+
+def test_state_dict_matches_hf_names_and_freezing_surface(pkg):
+    cfg = pkg.get_config("hostile")
+    m = pkg.SiglipVisionModelHIP(cfg, compute_dtype="fp32")
+    ref_shapes = pkg.weights.param_shapes(cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref_shapes.keys())       # HF SiglipVisionModel key order and names
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref_shapes[k]), k
+    assert sum(p.numel() for p in m.parameters()) == cfg.num_params()
+    seeded = pkg.weights.seeded_state_dict(cfg, 1)
+    m.load_state_dict(seeded)
+    m.load_state_dict({"vision_model." + k: v for k, v in seeded.items()})   # transformers-4.x prefixed keys
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(seeded.items())[:-1]})        # strict by default
+    # the reference's freezing code (Siglip2sidafrozen.py:757-768) runs unchanged
+    for p in m.vision_model.embeddings.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(m.vision_model.encoder.layers):
+        for p in layer.parameters():
+            p.requires_grad = i >= 1
+    assert m.config.hidden_size == 144
+    assert hasattr(m, "gradient_checkpointing_enable")
+    m.gradient_checkpointing_enable()
+    assert not m.embeddings.patch_embedding.weight.requires_grad
+    assert m.encoder.layers[1].mlp.fc1.weight.requires_grad
+    # no CPU fallback: calling the model on CPU tensors is an error, not a silent slow path
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(pixel_values=torch.zeros(1, 3, 42, 42))
+
+
+def test_named_configs_and_flop_model(pkg):
+    so = pkg.get_config("so400m-patch14-384")
+    assert (so.hidden_size, so.intermediate_size, so.num_hidden_layers, so.head_dim, so.native_grid) == \
+        (1152, 4304, 27, 72, 27)
+    # BASELINE.md §2 figures
+    assert abs(so.fwd_flops_per_image() / 1e9 - 670.35) < 0.01
+    assert abs(so.train_flops_per_image() / 1e12 - 2.0110) < 1e-3
+    base = pkg.get_config("base-patch16-224")
+    assert abs(base.fwd_flops_per_image() / 1e9 - 35.42) < 0.01
+    assert abs(so.num_params() / 1e6 - 428.2) < 0.1 and abs(base.num_params() / 1e6 - 92.9) < 0.1
+    with pytest.raises(KeyError):
+        pkg.get_config("no-such-model")
+    with pytest.raises(ValueError):
+        pkg.SiglipVisionConfig(hidden_size=100, num_attention_heads=3)
+    for name in ("ViT-B-16-SigLIP", "ViT-L-16-SigLIP-384", "ViT-SO400M-16-SigLIP2-512",
+                 "google/siglip2-large-patch16-384"):
+        assert pkg.get_config(name).hidden_size in (768, 1024, 1152)
+
+
+def test_from_pretrained_local_dir_and_open_clip_factory_errors(pkg, tmp_path):
+    import json
+    from safetensors.torch import save_file
+    cfg = pkg.get_config("tiny")
+    sd = pkg.weights.seeded_state_dict(cfg, 2)
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"vision_config": cfg.to_dict()}))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    m = pkg.SiglipVisionModelHIP.from_pretrained(str(d), compute_dtype="fp32")
+    assert torch.equal(m.state_dict()["head.probe"], sd["head.probe"])
+    m2 = pkg.SiglipVisionModelHIP.from_pretrained("tiny")
+    assert m2.config.num_hidden_layers == 3
+    with pytest.raises(OSError):
+        pkg.SiglipVisionModelHIP.from_pretrained("google/not-a-model")
