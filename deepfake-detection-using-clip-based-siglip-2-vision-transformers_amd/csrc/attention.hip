@@ -207,25 +207,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // ======================================================================================================
 // backward: delta = rowsum(dO ∘ O)
 // ======================================================================================================
+// One wave per token row: 16-byte coalesced loads of the whole [H*dh] row, per-chunk partial sums, then a
+// segmented sum of the dh/8 chunks of each head.  HBM-bound: 2 * D * 2 bytes per token.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                          float* __restrict__ delta, int B, int H, int N, int dh) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)B * N * H;
-  if (idx >= total) return;
-  const int h = (int)(idx % H);
-  const size_t tok = idx / H;  // b*N + i
-  const int b = (int)(tok / N), i = (int)(tok - (size_t)b * N);
-  const bf16* o = O + tok * ((size_t)H * dh) + h * dh;
-  const bf16* d = dO + tok * ((size_t)H * dh) + h * dh;
-  float acc = 0.f;
-  for (int j = 0; j < dh; j += 8) {
-    float a[8], g[8];
-    Vec<bf16, 8>::ld(o + j, a);
-    Vec<bf16, 8>::ld(d + j, g);
+  __shared__ float part[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t tok = (size_t)blockIdx.x * 4 + w;
+  const size_t ntok = (size_t)B * N;
+  const int D = H * dh, nch = D >> 3, cph = dh >> 3;  // chunks per row, chunks per head
+  if (tok < ntok) {
+    const bf16* o = O + tok * D;
+    const bf16* d = dO + tok * D;
+    for (int c = lane; c < nch; c += 64) {
+      float a[8], g[8];
+      Vec<bf16, 8>::ld(o + c * 8, a);
+      Vec<bf16, 8>::ld(d + c * 8, g);
+      float acc = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc = fmaf(a[r], g[r], acc);
+      for (int r = 0; r < 8; ++r) acc = fmaf(a[r], g[r], acc);
+      part[w][c] = acc;
+    }
   }
-  delta[((size_t)b * H + h) * N + i] = acc;
+  __builtin_amdgcn_wave_barrier();
+  if (tok < ntok) {
+    const int b = (int)(tok / N), i = (int)(tok - (size_t)b * N);
+    for (int h = lane; h < H; h += 64) {
+      float acc = 0.f;
+      for (int c = 0; c < cph; ++c) acc += part[w][h * cph + c];
+      delta[((size_t)b * H + h) * N + i] = acc;
+    }
+  }
 }
 
 // ======================================================================================================
@@ -527,9 +539,9 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   using C = AttnCfg<DP>;
   const float scale = 1.0f / sqrtf((float)dh);
   const float c = scale * 1.4426950408889634f;
-  const size_t total = (size_t)B * N * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, delta, B, H,
-                     N, dh);
+  const size_t ntok = (size_t)B * N;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, out, dout, delta, B, H, N,
+                     dh);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   constexpr int smem_kv = 2 * (2 * 32 * C::DSTR + 2 * 32 * 4);
@@ -549,6 +561,7 @@ static bool attn_shape_ok(int N, int dh, int DP, int H) {
   if (DP != 16 && DP != 32 && DP != 48 && DP != 64 && DP != 80 && DP != 96) return false;
   if ((size_t)N * DP * 2 >= (1ull << 31)) return false;
   if ((size_t)N * H * dh * 2 >= (1ull << 31)) return false;
+  if (H * dh > 2048) return false;  // delta kernel: 256 chunks of 8 per row
   return true;
 }
 

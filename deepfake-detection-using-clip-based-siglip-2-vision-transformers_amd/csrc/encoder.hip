@@ -62,7 +62,7 @@ struct Layout {
   size_t a_pstats, a_lastlp, a_kvh, a_qp, a_probs, a_ao, a_h0, a_hstats, a_hl, a_hu, a_ha;
   size_t act_total;
   // backward scratch (ws)
-  size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_lnpart, w_cspart, w_dlast;
+  size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_lnpart, w_cspart, w_dlast, w_gsum, w_csum;
   size_t w_hg, w_hdu, w_hdh, w_hdao, w_hdqpart, w_hdqp, w_hdh0;
   size_t ws_bwd_total;
   size_t saved_total, ws_total, ws_act_off;
@@ -113,7 +113,9 @@ struct Layout {
       w_dh = w.take(Mz * D * es);
       w_dqkv = w.take(Mz * 3 * D * es);
       w_delta = w.take((size_t)B * c->H * N * 4);
-      w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 2 * D * 4);
+      w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 3 * D * 4);
+      w_gsum = w.take(D * 4);        // column sums of the current d hidden_states (bias grad of the GEMM below)
+      w_csum = w.take(widest * 4);   // fused column sums coming out of a GEMM epilogue
       w_cspart = w.take((size_t)colsum_chunks(M) * widest * 4);
       w_dlast = w.take(Mz * D * 4);
       w_hg = w.take((size_t)B * D * es);
@@ -124,7 +126,7 @@ struct Layout {
       w_hdqp = w.take(D * 4);
       w_hdh0 = w.take((size_t)B * D * 4);
     } else {
-      w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_lnpart = w_cspart = w_dlast = 0;
+      w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_lnpart = w_cspart = w_dlast = w_gsum = w_csum = 0;
       w_hg = w_hdu = w_hdh = w_hdao = w_hdqpart = w_hdqp = w_hdh0 = 0;
     }
     ws_bwd_total = w.off;
@@ -483,18 +485,20 @@ int bias_grad(sgl_ctx* ctx, const Layout& lay, void* ws, const void* in, int ld,
   return SGL_OK;
 }
 
-// LayerNorm backward + dgamma/dbeta reduction
+// LayerNorm backward + dgamma/dbeta reduction.  colsum_out (nullable, [D]) (+)= column sums of the dx written,
+// i.e. the bias gradient of the Linear whose output gradient dx is (col_acc selects add vs overwrite).
 int ln_backward(sgl_ctx* ctx, const Layout& lay, void* ws, const void* dy, int dy_dt, const float* x, const float* stats,
                 int rows, const float* gamma, const float* dres, float* dx, void* dx_lp, float* dgamma, float* dbeta,
-                int accumulate, hipStream_t s) {
+                int accumulate, hipStream_t s, float* colsum_out = nullptr, int col_acc = 0) {
   const int D = ctx->D;
-  const bool want = dgamma || dbeta;
+  const bool want = dgamma || dbeta || colsum_out;
   const int nblk = layernorm_bwd_blocks(rows);
   float* part = reinterpret_cast<float*>(at(ws, lay.w_lnpart));
   CK(layernorm_bwd(dy, dy_dt, D, x, stats, stats + rows, gamma, dres, dx, dx_lp, ctx->dt, want ? part : nullptr, nblk,
                    rows, D, s));
-  if (dgamma) CK(reduce_partials(part, nblk, 2 * D, dgamma, D, accumulate, s));
-  if (dbeta) CK(reduce_partials(part + D, nblk, 2 * D, dbeta, D, accumulate, s));
+  if (dgamma) CK(reduce_partials(part, nblk, 3 * D, dgamma, D, accumulate, s));
+  if (dbeta) CK(reduce_partials(part + D, nblk, 3 * D, dbeta, D, accumulate, s));
+  if (colsum_out) CK(reduce_partials(part + 2 * D, nblk, 3 * D, colsum_out, D, col_acc, s));
   return SGL_OK;
 }
 
@@ -530,6 +534,7 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   void* gbuf = at(ws, lay.w_g);
   const float* hsL = hidden_states + (size_t)ctx->L * M * D;
   const float* dlast = d_last_hidden;  // gradient w.r.t. post_layernorm output
+  float* gsum = reinterpret_cast<float*>(at(ws, lay.w_gsum));
 
   if (ctx->cfg.use_head && d_pooled) {
     float* dlast_buf = reinterpret_cast<float*>(at(ws, lay.w_dlast));
@@ -616,13 +621,15 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   // post_layernorm backward -> dx (fp32) and its low-precision copy (A operand of the last block's GEMMs)
   if (dlast) {
     RET(ln_backward(ctx, lay, ws, dlast, DT_F32, hsL, reinterpret_cast<const float*>(act + lay.a_pstats), M,
-                    w->post_ln_w, d_tap_last, dx, gbuf, g->post_ln_w, g->post_ln_b, acc, s));
+                    w->post_ln_w, d_tap_last, dx, gbuf, g->post_ln_w, g->post_ln_b, acc, s, gsum, 0));
   } else if (d_tap_last) {
     CK(copy_f32(d_tap_last, dx, (size_t)M * D, s));
     CK(cast_f32(d_tap_last, gbuf, dt, (size_t)M * D, s));
+    CK(colsum(gbuf, dt, D, M, D, D, reinterpret_cast<float*>(at(ws, lay.w_cspart)), gsum, 0, s));
   } else {
     CK(hipMemsetAsync(dx, 0, (size_t)M * D * 4, s));
     CK(hipMemsetAsync(gbuf, 0, (size_t)M * D * ctx->es, s));
+    CK(hipMemsetAsync(gsum, 0, (size_t)D * 4, s));
   }
   return SGL_OK;
 }
@@ -652,16 +659,23 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   void* dqkv = at(ws, lay.w_dqkv);
 
   // ---- MLP: x_out = xmid + fc2(gelu(fc1(LN2 xmid)))          gbuf = lowp(d x_out)
+  float* gsum = reinterpret_cast<float*>(at(ws, lay.w_gsum));   // column sums of dx, left by the producer of dx
+  float* csum = reinterpret_cast<float*>(at(ws, lay.w_csum));
+  const bool fuse_cs = (dt == DT_BF16) && lg.fc1_b;  // MFMA epilogue adds colsum(du); strict mode uses colsum()
   {
     EpiParams p;
     p.out = du;
     p.ldo = Ip;
     p.aux = lb + lay.r_u;
     p.ldaux = Ip;
+    if (fuse_cs) {
+      CK(hipMemsetAsync(csum, 0, (size_t)Ip * 4, s));
+      p.colsum = csum;
+    }
     CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.w2_t), D, M, Ip, D, EPI_GELU_BWD, dt, p, s));
   }
   if (lg.fc2_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_a, Ip, M, D, I, lg.fc2_w, I, acc, s));
-  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, lg.fc2_b, acc, s));
+  if (lg.fc2_b) CK(batch_sum(gsum, 1, (size_t)D, lg.fc2_b, acc, s));
   {
     EpiParams p;
     p.out = dhb;
@@ -669,10 +683,13 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     CK(gemm_nt(ctx, du, Ip, at(shadow, sl.w1_t), Ip, M, D, Ip, EPI_STORE, dt, p, s));
   }
   if (lg.fc1_w) CK(gemm_tn(ctx, du, Ip, lb + lay.r_h2, D, M, I, D, lg.fc1_w, D, acc, s));
-  RET(bias_grad(ctx, lay, ws, du, Ip, M, Ip, I, lg.fc1_b, acc, s));
-  // LN2 backward: dx := dx + LN2'(dh2);  gbuf := lowp(dx)
+  if (fuse_cs)
+    CK(batch_sum(csum, 1, (size_t)I, lg.fc1_b, acc, s));
+  else
+    RET(bias_grad(ctx, lay, ws, du, Ip, M, Ip, I, lg.fc1_b, acc, s));
+  // LN2 backward: dx := dx + LN2'(dh2);  gbuf := lowp(dx);  colsum(dx) is the out_proj bias gradient
   RET(ln_backward(ctx, lay, ws, dhb, dt, xmid, reinterpret_cast<const float*>(lb + lay.r_stats2), M, lw.ln2_w, dx, dx,
-                  gbuf, lg.ln2_w, lg.ln2_b, acc, s));
+                  gbuf, lg.ln2_w, lg.ln2_b, acc, s, lg.o_b, acc));
 
   // ---- attention: xmid = x_in + out_proj(attn(qkv(LN1 x_in)))
   {
@@ -682,7 +699,6 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.wo_t), D, M, D, D, EPI_STORE, dt, p, s));
   }
   if (lg.o_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_attn, D, M, D, D, lg.o_w, D, acc, s));
-  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, lg.o_b, acc, s));
   {
     const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
     const char* q = lb + lay.r_qkv;
@@ -711,7 +727,7 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     p.ldo = D;
     CK(gemm_nt(ctx, dqkv, 3 * D, at(shadow, sl.wqkv_t), 3 * D, M, D, 3 * D, EPI_STORE, dt, p, s));
     RET(ln_backward(ctx, lay, ws, dhb, dt, x_in, reinterpret_cast<const float*>(lb + lay.r_stats1), M, lw.ln1_w, dx, dx,
-                    gbuf, lg.ln1_w, lg.ln1_b, acc, s));
+                    gbuf, lg.ln1_w, lg.ln1_b, acc, s, gsum, 0));
   }
   return SGL_OK;
 }
@@ -729,7 +745,7 @@ int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, i
   float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
   void* gbuf = at(ws, lay.w_g);  // low-precision copy of dx (written by the last LN1 backward / begin)
   if (g->patch_w) CK(gemm_tn(ctx, gbuf, D, act + lay.a_im2col, ctx->Kp, M, D, ctx->K0, g->patch_w, ctx->K0, acc, s));
-  RET(bias_grad(ctx, lay, ws, gbuf, D, M, D, D, g->patch_b, acc, s));
+  if (g->patch_b) CK(batch_sum(reinterpret_cast<const float*>(at(ws, lay.w_gsum)), 1, (size_t)D, g->patch_b, acc, s));
   if (g->pos) {
     if (lay.gh == ctx->g0 && lay.gw == ctx->g0) {
       CK(batch_sum(dx, B, (size_t)N * D, g->pos, acc, s));
@@ -784,11 +800,11 @@ int sgl_op_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const flo
                          const float* gamma, const float* dres, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
                          float* dbeta, float* scratch, size_t scratch_bytes, int M, int D, sgl_stream stream) {
   const int nblk = layernorm_bwd_blocks(M);
-  if (scratch_bytes < (size_t)nblk * 2 * D * 4) return SGL_ERR_WORKSPACE;
+  if (scratch_bytes < (size_t)nblk * 3 * D * 4) return SGL_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   CKV(layernorm_bwd(dy, dy_dtype, D, x, mean, rstd, gamma, dres, dx, dx_lp, lp_dtype, scratch, nblk, M, D, s));
-  if (dgamma) CKV(reduce_partials(scratch, nblk, 2 * D, dgamma, D, 0, s));
-  if (dbeta) CKV(reduce_partials(scratch + D, nblk, 2 * D, dbeta, D, 0, s));
+  if (dgamma) CKV(reduce_partials(scratch, nblk, 3 * D, dgamma, D, 0, s));
+  if (dbeta) CKV(reduce_partials(scratch + D, nblk, 3 * D, dbeta, D, 0, s));
   return SGL_OK;
 }
 

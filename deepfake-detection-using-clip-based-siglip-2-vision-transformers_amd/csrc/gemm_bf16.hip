@@ -74,6 +74,9 @@ __device__ __forceinline__ void store_tile(char* smem, f32x4 (&acc)[4][4], int w
   // bf16 outputs: 8 columns (16 B) per lane, four 256-B rows per wave instruction
   constexpr int NV = (sizeof(TOut) == 4) ? 4 : 8;
   constexpr int CPR = G_BN / NV;
+  float csum[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) csum[j] = 0.f;
 #pragma unroll
   for (int q = 0; q < (G_BM * CPR) / 256; ++q) {
     const int c = t + q * 256;
@@ -83,6 +86,25 @@ __device__ __forceinline__ void store_tile(char* smem, f32x4 (&acc)[4][4], int w
       float v[NV];
       Vec<float, NV>::ld(ct + row * G_CT_LD + col, v);
       epi_apply<EPI, TOut, NV>(p, grow, gcol, N, v);
+      if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) csum[j] += v[j];
+      }
+    }
+  }
+  if constexpr (EPI == EPI_GELU_BWD) {
+    if (p.colsum) {  // fused bias gradient (see gemm_bf16_v2.hip)
+      __syncthreads();
+      constexpr int GROUPS = 256 / CPR;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) ct[(t / CPR) * G_BN + (t % CPR) * NV + j] = csum[j];
+      __syncthreads();
+      if (t < G_BN && n0 + t < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < GROUPS; ++gI) s += ct[gI * G_BN + t];
+        atomicAdd(p.colsum + n0 + t, s);
+      }
     }
   }
 }

@@ -44,6 +44,9 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
   const int g = lane >> 4, c16 = lane & 15;
   constexpr int NV = (sizeof(TOut) == 4) ? 4 : 8;
   constexpr int CPR = T_BN / NV;
+  float csum[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) csum[j] = 0.f;
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     __syncthreads();
@@ -85,6 +88,27 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
         float v[NV];
         Vec<float, NV>::ld(ct + row * T_CT_LD + col, v);
         epi_apply<EPI, TOut, NV>(p, grow, gcol, N, v);
+        if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) csum[j] += v[j];
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_GELU_BWD) {
+    // fused bias gradient: every thread always owns the same NV columns (512 % CPR == 0); fold the 512/CPR row
+    // groups through LDS and add one value per column to p.colsum
+    if (p.colsum) {
+      __syncthreads();
+      constexpr int GROUPS = 512 / CPR;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) ct[(t / CPR) * T_BN + (t % CPR) * NV + j] = csum[j];
+      __syncthreads();
+      if (t < T_BN && n0 + t < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < GROUPS; ++gI) s += ct[gI * T_BN + t];
+        atomicAdd(p.colsum + n0 + t, s);
       }
     }
   }

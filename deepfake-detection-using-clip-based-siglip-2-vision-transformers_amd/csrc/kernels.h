@@ -32,13 +32,16 @@ struct EpiParams {
   float alpha = 1.0f;
   int accumulate = 0;
   int atomic = 0;
+  // EPI_GELU_BWD on the MFMA kernels: when non-null, column sums of the fp32 output tile are atomically added here
+  // (= the bias gradient of the GEMM whose output gradient is being produced); must be zeroed/initialised by the host
+  float* colsum = nullptr;
 };
 
 // ---- layernorm.hip -----------------------------------------------------------------------------------
 hipError_t layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype, int ldy,
                          float* mean, float* rstd, int M, int D, float eps, hipStream_t s);
 int layernorm_bwd_blocks(int M);
-// partial: [nblk][2*D] floats (dgamma then dbeta per block)
+// partial: [nblk][3*D] floats per block: dgamma, dbeta, column sums of the dx this call wrote
 hipError_t layernorm_bwd(const void* dy, int dy_dtype, int lddy, const float* x, const float* mean,
                          const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_lp,
                          int lp_dtype, float* partial, int nblk, int M, int D, hipStream_t s);

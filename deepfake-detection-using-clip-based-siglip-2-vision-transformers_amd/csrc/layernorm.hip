@@ -86,23 +86,24 @@ hipError_t layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 
 // Backward.  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  optional "+ dres" fuses the
 // residual-branch gradient; optional low-precision copy of dx feeds the next backward GEMM's A operand.
-// dgamma/dbeta: per-lane register partials over the block's rows -> LDS -> partial[block][2D].
+// dgamma/dbeta/colsum(dx): per-lane register partials over the block's rows -> LDS -> partial[block][3D].
 template <typename TDy, typename TLp, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, TLp* __restrict__ dx_lp,
                                                      float* __restrict__ partial, int M, int D) {
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][2][D]
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][3][D]
   const int lane = lane_id(), w = wave_id();
   const int nv = D >> 2;
-  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], ds[LN_MAXV];  // ds: column sums of the dx written
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     dg[i] = z;
     db[i] = z;
+    ds[i] = z;
     gam[i] = (c < nv) ? reinterpret_cast<const f32x4*>(gamma)[c] : z;
   }
   const float invD = 1.0f / (float)D;
@@ -148,29 +149,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
           for (int j = 0; j < 4; ++j) o[j] += r[j];
         }
         Vec<float, 4>::st(dxr + c * 4, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ds[i][j] += o[j];
         if (dx_lp) Vec<TLp, 4>::st(dx_lp + (size_t)row * D + c * 4, o);
       }
     }
   }
   if (!partial) return;
-  float* mine = ln_smem + (size_t)w * 2 * D;
+  float* mine = ln_smem + (size_t)w * 3 * D;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
       reinterpret_cast<f32x4*>(mine)[c] = dg[i];
       reinterpret_cast<f32x4*>(mine + D)[c] = db[i];
+      reinterpret_cast<f32x4*>(mine + 2 * D)[c] = ds[i];
     }
   }
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * 2 * D;
-  for (int j = threadIdx.x; j < 2 * D; j += 256)
-    out[j] = (ln_smem[j] + ln_smem[2 * D + j]) + (ln_smem[4 * D + j] + ln_smem[6 * D + j]);
+  float* out = partial + (size_t)blockIdx.x * 3 * D;
+  for (int j = threadIdx.x; j < 3 * D; j += 256)
+    out[j] = (ln_smem[j] + ln_smem[3 * D + j]) + (ln_smem[6 * D + j] + ln_smem[9 * D + j]);
 }
 
 int layernorm_bwd_blocks(int M) {
   int b = (M + 3) / 4;
-  return b < 1 ? 1 : (b > 512 ? 512 : b);
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 
 template <typename TDy, typename TLp>
@@ -178,7 +182,7 @@ static hipError_t ln_bwd_launch2(const void* dy, int lddy, const float* x, const
                                  const float* gamma, const float* dres, float* dx, void* dx_lp, float* partial,
                                  int nblk, int M, int D, hipStream_t s) {
   dim3 grid(nblk), block(256);
-  const size_t smem = (size_t)4 * 2 * D * sizeof(float);
+  const size_t smem = (size_t)4 * 3 * D * sizeof(float);
 #define SGL_LNB(V)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<TDy, TLp, V>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma, \
                      dres, dx, (TLp*)dx_lp, partial, M, D)

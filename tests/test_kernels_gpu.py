@@ -69,7 +69,7 @@ def test_layernorm_fwd_bwd(lib, M, D, odt):
     dxlp = torch.empty(M, D, device=dev, dtype=tdt)
     dg = torch.empty(D, device=dev)
     db = torch.empty(D, device=dev)
-    scratch = torch.empty(1024 * 2 * D, device=dev)
+    scratch = torch.empty(1024 * 3 * D, device=dev)
     ok(lib.sgl_op_layernorm_bwd(P(dy), odt, P(x), P(mean), P(rstd), P(g), P(dres), P(dx), P(dxlp), odt, P(dg), P(db),
                                 P(scratch), scratch.numel() * 4, M, D, stream()))
     ref.backward(dy.float())
