@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = fast_exp2(c * (m_run - m_new));
+    const bool grew = __any(m_new > m_run);  // wave-uniform: alpha == 1 exactly in every lane when nothing grew
+    const float alpha = grew ? fast_exp2(c * (m_run - m_new)) : 1.0f;
     const float mc = m_new * c;
     float rs = 0.f;
 #pragma unroll
@@ -167,10 +168,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     }
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if (grew) {
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+      for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     bf16x8 pb[4];
     pb[0] = pack8(s0, 0);
     pb[1] = pack8(s0, 8);

@@ -496,9 +496,7 @@ int ln_backward(sgl_ctx* ctx, const Layout& lay, void* ws, const void* dy, int d
   float* part = reinterpret_cast<float*>(at(ws, lay.w_lnpart));
   CK(layernorm_bwd(dy, dy_dt, D, x, stats, stats + rows, gamma, dres, dx, dx_lp, ctx->dt, want ? part : nullptr, nblk,
                    rows, D, s));
-  if (dgamma) CK(reduce_partials(part, nblk, 3 * D, dgamma, D, accumulate, s));
-  if (dbeta) CK(reduce_partials(part + D, nblk, 3 * D, dbeta, D, accumulate, s));
-  if (colsum_out) CK(reduce_partials(part + 2 * D, nblk, 3 * D, colsum_out, D, col_acc, s));
+  CK(reduce_partials3(part, nblk, 3 * D, dgamma, dbeta, colsum_out, D, accumulate, accumulate, col_acc, s));
   return SGL_OK;
 }
 

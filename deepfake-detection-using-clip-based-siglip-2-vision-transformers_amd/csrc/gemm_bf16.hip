@@ -344,7 +344,8 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if ((lda % 8) || (ldb % 8) || (K % 8) || K <= 0) return hipErrorInvalidValue;
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
- if (gemm_generation() == 2 && M >= 2048 && N >= 256) return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
+  if (gemm_generation() >= 2 && M >= 2048 && N >= 256)
+    return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
   const bf16* A = (const bf16*)A_;
   const bf16* B = (const bf16*)B_;
 #define SGL_CASE(E)                                                                   \
@@ -382,10 +383,10 @@ hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mr
       return hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
     return hipSuccess;
   }
-  if (gemm_generation() == 2 && N1 >= 512 && N2 >= 512 && Mred >= 2048) {
+  if (gemm_generation() >= 2 && N1 >= 512 && N2 >= 512 && Mred >= 2048) {
     // 256x256 tiles, one workgroup per CU: split the token reduction until ~256 workgroups exist
+    // 256x256 tiles, one workgroup per CU (128 KiB LDS): keep tiles*splits <= 256 (a single full round)
     const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);
-    // one workgroup per CU (128 KiB LDS): keep tiles*splits <= 256 so the grid is a single full round
     int sp = 256 / tiles;
     if (sp < 1) sp = 1;
     const int max_sp = Mred / 1024 > 0 ? Mred / 1024 : 1;

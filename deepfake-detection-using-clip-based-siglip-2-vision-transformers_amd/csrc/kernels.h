@@ -48,6 +48,9 @@ hipError_t layernorm_bwd(const void* dy, int dy_dtype, int lddy, const float* x,
 // out[j] (+)= sum_b partial[b*stride + j], j < n
 hipError_t reduce_partials(const float* partial, int nblk, int stride, float* out, int n, int accumulate,
                            hipStream_t s);
+// o_k[j] (+)= sum_b partial[b*stride + k*n + j] for k = 0,1,2 in one launch (null outputs skipped)
+hipError_t reduce_partials3(const float* partial, int nblk, int stride, float* o0, float* o1, float* o2, int n, int a0,
+                            int a1, int a2, hipStream_t s);
 
 // ---- elementwise.hip ---------------------------------------------------------------------------------
 hipError_t im2col(const float* pix, int channels_last, void* out, int out_dtype, int B, int H, int W, int P,

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, TLp* __restrict__ dx_lp,
                                                      float* __restrict__ partial, int M, int D) {
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][3][D]
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][D]
   const int lane = lane_id(), w = wave_id();
   const int nv = D >> 2;
   f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], ds[LN_MAXV];  // ds: column sums of the dx written
@@ -156,25 +156,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     }
   }
   if (!partial) return;
-  float* mine = ln_smem + (size_t)w * 3 * D;
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      reinterpret_cast<f32x4*>(mine)[c] = dg[i];
-      reinterpret_cast<f32x4*>(mine + D)[c] = db[i];
-      reinterpret_cast<f32x4*>(mine + 2 * D)[c] = ds[i];
-    }
-  }
-  __syncthreads();
+  // cross-wave fold through one [4][D] LDS buffer, reused for the three vectors (keeps LDS at 4*D*4 bytes so that
+  // occupancy is set by registers, not LDS)
+  float* mine = ln_smem + (size_t)w * D;
   float* out = partial + (size_t)blockIdx.x * 3 * D;
-  for (int j = threadIdx.x; j < 3 * D; j += 256)
-    out[j] = (ln_smem[j] + ln_smem[3 * D + j]) + (ln_smem[6 * D + j] + ln_smem[9 * D + j]);
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) reinterpret_cast<f32x4*>(mine)[c] = (ph == 0) ? dg[i] : ((ph == 1) ? db[i] : ds[i]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += 256)
+      out[ph * D + j] = (ln_smem[j] + ln_smem[D + j]) + (ln_smem[2 * D + j] + ln_smem[3 * D + j]);
+    __syncthreads();
+  }
 }
 
 int layernorm_bwd_blocks(int M) {
   int b = (M + 3) / 4;
-  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  return b < 1 ? 1 : (b > 768 ? 768 : b);
 }
 
 template <typename TDy, typename TLp>
@@ -182,7 +184,7 @@ static hipError_t ln_bwd_launch2(const void* dy, int lddy, const float* x, const
                                  const float* gamma, const float* dres, float* dx, void* dx_lp, float* partial,
                                  int nblk, int M, int D, hipStream_t s) {
   dim3 grid(nblk), block(256);
-  const size_t smem = (size_t)4 * 3 * D * sizeof(float);
+  const size_t smem = (size_t)4 * D * sizeof(float);
 #define SGL_LNB(V)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<TDy, TLp, V>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma, \
                      dres, dx, (TLp*)dx_lp, partial, M, D)
@@ -238,6 +240,46 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     for (int k = 0; k < 8; ++k) r += red[k][c];
     out[j] = accumulate ? out[j] + r : r;
   }
+}
+
+// three outputs in one launch: out_k[j] (+)= sum_b partial[b*stride + k*n + j]  (null outputs are skipped)
+__global__ __launch_bounds__(256) void reduce_partials3_kernel(const float* __restrict__ partial, int nblk, int stride,
+                                                               float* __restrict__ o0, float* __restrict__ o1,
+                                                               float* __restrict__ o2, int n, int a0, int a1, int a2) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  const int which = j / n, jj = j - which * n;
+  float* o = which == 0 ? o0 : (which == 1 ? o1 : o2);
+  const int acc = which == 0 ? a0 : (which == 1 ? a1 : a2);
+  const bool live = (j < 3 * n) && o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (live) {
+    int b = g;
+    for (; b + 24 < nblk; b += 32) {
+      s0 += partial[(size_t)b * stride + j];
+      s1 += partial[(size_t)(b + 8) * stride + j];
+      s2 += partial[(size_t)(b + 16) * stride + j];
+      s3 += partial[(size_t)(b + 24) * stride + j];
+    }
+    for (; b < nblk; b += 8) s0 += partial[(size_t)b * stride + j];
+  }
+  red[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && live) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][c];
+    o[jj] = acc ? o[jj] + r : r;
+  }
+}
+
+hipError_t reduce_partials3(const float* partial, int nblk, int stride, float* o0, float* o1, float* o2, int n, int a0,
+                            int a1, int a2, hipStream_t s) {
+  if (n == 0 || (!o0 && !o1 && !o2)) return hipSuccess;
+  hipLaunchKernelGGL(reduce_partials3_kernel, dim3((3 * n + 31) / 32), dim3(256), 0, s, partial, nblk, stride, o0, o1,
+                     o2, n, a0, a1, a2);
+  return hipGetLastError();
 }
 
 hipError_t reduce_partials(const float* partial, int nblk, int stride, float* out, int n, int accumulate,
