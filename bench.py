@@ -95,36 +95,52 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
         tot_f += fl
         del A, Bw, out, out2, res_t
     achieved = tot_f / tot_t / 1e12
-    return {"bound": "mfma", "kernel": "sgl::gemm_nt_kernel (bf16 MFMA NT GEMM, fwd shapes of one block)",
+    return {"bound": "mfma", "kernel": "sgl::gemm_nt2_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None, "per_shape": per}
 
 
-def cpu_baseline(pkg, cfg, res, steps):
-    """The CPU oracle (port of the HF path, validated against HF in tests/) timed on this box's host cores."""
-    oracle = entry.load_oracle()
-    cores = os.cpu_count() or 1
+def host_cores() -> int:
+    """Cores this process may really use: cgroup quota (cpu.max) if set, else the affinity mask."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(pkg, cfg, res, steps):
+    """The CPU oracle (port of the HF path, validated against HF in tests/) timed on this box's host cores, on a
+    bounded sample of the same workload (batch 2, a few steps)."""
+    oracle = entry.load_oracle()
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = 2
     sd = {k: v.clone().requires_grad_(True) for k, v in pkg.weights.seeded_state_dict(cfg, seed=0).items()}
     x = pkg.weights.seeded_pixels(B, res, res, seed=1234)
 
-    def step():
-        out = oracle.vision_forward(x, sd, cfg, False, True)
+    def step(xb):
+        out = oracle.vision_forward(xb, sd, cfg, False, True)
         out["pooler_output"].square().mean().backward()
         for v in sd.values():
             v.grad = None
-    step()
+    print(f"[bench] cpu_baseline: warm-up on {cores} cores ...", file=sys.stderr, flush=True)
+    step(x[:1])
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(x)
+        print(f"[bench] cpu_baseline: step {i + 1}/{steps} at {time.perf_counter() - t0:.1f} s", file=sys.stderr,
+              flush=True)
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(B / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{cfg_name_of(cfg)} fp32 oracle, batch {B}, {steps} timed fwd+bwd steps after 1 warm-up"}
+            "sample": f"{cfg_name_of(cfg)} fp32 oracle, batch {B}, {steps} timed fwd+bwd steps after a 1-image warm-up"}
 
 
 def cfg_name_of(cfg):
@@ -202,6 +218,8 @@ def main():
         "train_tflop_per_image": round(train_flops / 1e12, 4),
     }
     if rank == 0:
+        print(f"[bench] {value:.1f} images/s, {ms_per_step:.1f} ms/step; measuring kernel roofline + CPU baseline ...",
+              file=sys.stderr, flush=True)
         if world == 1:
             line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
             del model
