@@ -1,0 +1,525 @@
+"""Reference-owned heads, decoder and losses that sit on the encoder's outputs.
+
+These are the small PyTorch modules the reference defines itself around the third-party ViT.  They consume the
+HIP encoder's outputs through autograd; parameter names match the reference's modules so its checkpoints load
+(`decoder.projs.N.proj.weight`, `cls_head.weight`, `se.0.weight`, `classifier.N.weight`, `mlp.0.weight`, …).
+Parity is pinned by `tests/golden/heads_*.npz`, produced by `oracle/gen_golden_heads.py`, which executes the
+reference's own class definitions (lifted from its source text in the build container) on seeded weights/inputs.
+
+The decoder is the only piece with real HBM traffic; here the 1x1 `head` conv is applied BEFORE
+the bilinear up-sampling — exact in real arithmetic because bilinear weights sum to one — so the
+(B, E, img, img) tensor of the reference (151 MB per image at E=512, 384²) is never materialised.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import isqrt_exact
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SID_Set multi-task model  (Siglip2sidafrozen.py:693-803)
+# ---------------------------------------------------------------------------------------------------------
+class _TapProj(nn.Module):
+    """`LinearProj` (:693-696): keeps the `.proj` sub-module name of the reference checkpoints."""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.proj = nn.Linear(in_dim, out_dim)
+
+    def forward(self, x):
+        return self.proj(x)
+
+
+class SegFormerMaskDecoder(nn.Module):
+    """SegFormer-style mask decoder (`SegFormerStrongDecoder`, Siglip2sidafrozen.py:698-745).
+
+    per tap: Linear(D→E) → (B,E,g,g) → depthwise 3x3 → 1x1 → GELU; concat K taps → channel gate
+    (1x1 E·K→E·K/4 → GELU → 1x1 → sigmoid) ⊙ → 1x1 E·K→E → [1x1 E→1 ∘ bilinear up to target]."""
+
+    def __init__(self, in_dims: Sequence[int], embed_dim: int = 256, dropout_rate: float = 0.0,
+                 head_before_upsample: bool = True):
+        super().__init__()
+        k = len(in_dims)
+        self.projs = nn.ModuleList([_TapProj(d, embed_dim) for d in in_dims])
+        smooth = []
+        for _ in in_dims:
+            layers: List[nn.Module] = [nn.Conv2d(embed_dim, embed_dim, 3, padding=1, groups=embed_dim),
+                                       nn.Conv2d(embed_dim, embed_dim, 1), nn.GELU()]
+            if dropout_rate > 0:
+                layers.append(nn.Dropout2d(p=dropout_rate))
+            smooth.append(nn.Sequential(*layers))
+        self.smooth = nn.ModuleList(smooth)
+        self.fuse_attn = nn.Sequential(nn.Conv2d(embed_dim * k, (embed_dim * k) // 4, 1), nn.GELU(),
+                                       nn.Conv2d((embed_dim * k) // 4, embed_dim * k, 1), nn.Sigmoid())
+        fuse: List[nn.Module] = [nn.Conv2d(embed_dim * k, embed_dim, 1)]
+        if dropout_rate > 0:
+            fuse.append(nn.Dropout2d(p=dropout_rate))
+        self.fuse = nn.Sequential(*fuse)
+        self.head = nn.Conv2d(embed_dim, 1, 1)
+        self.head_before_upsample = head_before_upsample
+
+    def forward(self, hidden_list: Sequence[torch.Tensor], grid_hw: Tuple[int, int], target_size: int = 448):
+        gh, gw = grid_hw
+        feats = []
+        for proj, smooth, h in zip(self.projs, self.smooth, hidden_list):
+            x = proj(h).transpose(1, 2)
+            b, e, _ = x.shape
+            feats.append(smooth(x.reshape(b, e, gh, gw)))
+        x = torch.cat(feats, dim=1)
+        x = self.fuse(self.fuse_attn(x) * x)
+        if self.head_before_upsample:
+            return F.interpolate(self.head(x), size=(target_size, target_size), mode="bilinear", align_corners=False)
+        x = F.interpolate(x, size=(target_size, target_size), mode="bilinear", align_corners=False)
+        return self.head(x)
+
+
+class SigLIP2MTL(nn.Module):
+    """3-class (real / synthetic / tampered) + mask-localisation model (`SigLIP2_MTL`,
+    Siglip2sidafrozen.py:750-803) on the HIP encoder.  `forward(pixel_values) -> (cls_logit (B,3), seg_logits
+    (B,1,S,S))`.  Only the taps the decoder needs are requested from the encoder."""
+
+    def __init__(self, encoder: nn.Module, seg_layers: Sequence[int] = (2, 6, 10, -1), embed_dim: int = 256,
+                 dropout_rate: float = 0.0, freeze_below: Optional[int] = None):
+        super().__init__()
+        self.encoder = encoder
+        hid = encoder.config.hidden_size
+        if freeze_below is not None:  # frozen variant (:754-768): embeddings + blocks < freeze_below
+            for p in encoder.vision_model.embeddings.parameters():
+                p.requires_grad = False
+            for i, layer in enumerate(encoder.vision_model.encoder.layers):
+                for p in layer.parameters():
+                    p.requires_grad = i >= freeze_below
+        self.cls_head = (nn.Sequential(nn.Dropout(p=dropout_rate), nn.Linear(hid, 3)) if dropout_rate > 0
+                         else nn.Linear(hid, 3))
+        self.seg_layers = tuple(seg_layers)
+        self.decoder = SegFormerMaskDecoder([hid] * len(self.seg_layers), embed_dim=embed_dim,
+                                            dropout_rate=dropout_rate)
+
+    def forward(self, pixel_values):
+        n_layers = self.encoder.config.num_hidden_layers
+        idxs = [(i + 1 if i >= 0 else n_layers) for i in self.seg_layers]   # hs = [emb, h1..hL] (:790-793)
+        out = self.encoder(pixel_values=pixel_values, hidden_state_ids=idxs, interpolate_pos_encoding=True)
+        pooled = out.pooler_output if out.pooler_output is not None else out.last_hidden_state.mean(1)
+        cls_logit = self.cls_head(pooled).squeeze(1)
+        feats = list(out.hidden_states)
+        g = isqrt_exact(feats[0].shape[1])
+        seg_logits = self.decoder(feats, (g, g), target_size=int(pixel_values.shape[-1]))
+        return cls_logit, seg_logits
+
+
+# ---------------------------------------------------------------------------------------------------------
+# binary heads on the pooled embedding
+# ---------------------------------------------------------------------------------------------------------
+def l2_normalize(f: torch.Tensor, eps: float = 0.0) -> torch.Tensor:
+    """`f / f.norm(dim=-1, keepdim=True)` (cifake_binary_classifier.py:728, hidf_video_classifier.py:308);
+    eps=1e-6 is the `train_fusion_head_only.py:106` form."""
+    return f / (f.norm(dim=-1, keepdim=True) + eps)
+
+
+class SingleTokenAttention(nn.Module):
+    """`LightweightAttention` (cifake_binary_classifier.py:574-595) applied to a length-1 sequence."""
+
+    def __init__(self, dim: int, num_heads: int = 4):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        attn = ((qkv[0] @ qkv[1].transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        return self.proj((attn @ qkv[2]).transpose(1, 2).reshape(b, n, c))
+
+
+class CifakeBinaryHead(nn.Module):
+    """Head of `FastBinaryClassifier` (cifake_binary_classifier.py:640-698,727-749): L2-norm → LayerNorm →
+    (length-1 attention) → size-dependent MLP → scalar logit."""
+
+    def __init__(self, feature_dim: int, model_size: str = "small", dropout_rate: float = 0.1,
+                 use_lightweight_attention: bool = True):
+        super().__init__()
+        if use_lightweight_attention and model_size in ("tiny", "small"):
+            self.attention: Optional[nn.Module] = SingleTokenAttention(feature_dim, num_heads=4)
+        elif model_size == "large":
+            self.attention = nn.MultiheadAttention(feature_dim, min(8, feature_dim // 64), dropout=dropout_rate,
+                                                   batch_first=True)
+        else:
+            self.attention = None
+        d = feature_dim
+        if model_size == "tiny":
+            self.classifier = nn.Sequential(nn.Dropout(dropout_rate * 0.5), nn.Linear(d, 1))
+        elif model_size == "small":
+            self.classifier = nn.Sequential(nn.Linear(d, d // 4), nn.GELU(), nn.Dropout(dropout_rate),
+                                            nn.Linear(d // 4, 1))
+        else:
+            self.classifier = nn.Sequential(nn.Linear(d, d // 2), nn.GELU(), nn.Dropout(dropout_rate),
+                                            nn.Linear(d // 2, d // 4), nn.GELU(), nn.Dropout(dropout_rate * 0.5),
+                                            nn.Linear(d // 4, 1))
+        self.layer_norm = nn.LayerNorm(d)
+
+    def forward(self, features, return_features: bool = False):
+        f = self.layer_norm(l2_normalize(features))
+        if self.attention is not None:
+            f = f.unsqueeze(1)
+            f = self.attention(f) if isinstance(self.attention, SingleTokenAttention) else self.attention(f, f, f)[0]
+            f = f.squeeze(1)
+        return f if return_features else self.classifier(f).squeeze(-1)
+
+
+class VideoBinaryHead(nn.Module):
+    """Tail of `BinaryVideoClassifier` (hidf_video_classifier.py:276-320): per-frame L2-norm → mean over T →
+    LayerNorm / MLP → one logit per clip.  Input: per-frame embeddings (B*T, D)."""
+
+    def __init__(self, feature_dim: int, num_frames: int = 4, dropout_rate: float = 0.3):
+        super().__init__()
+        d = feature_dim
+        self.num_frames = num_frames
+        self.binary_classifier = nn.Sequential(
+            nn.LayerNorm(d), nn.Dropout(dropout_rate), nn.Linear(d, d // 2), nn.ReLU(),
+            nn.Dropout(dropout_rate * 0.67), nn.Linear(d // 2, d // 4), nn.ReLU(), nn.Dropout(dropout_rate * 0.33),
+            nn.Linear(d // 4, 1))
+
+    def forward(self, frame_features, batch_size: int):
+        f = l2_normalize(frame_features).view(batch_size, -1, frame_features.shape[-1])
+        return self.binary_classifier(f.mean(dim=1)).squeeze(-1)
+
+
+class SEBinaryHead(nn.Module):
+    """SE gate + MLP of `BinaryClassifier` (train_fusion_head_only.py:84-109): f·σ(W2 relu(W1 f)) → MLP."""
+
+    def __init__(self, dim: int = 1024):
+        super().__init__()
+        self.se = nn.Sequential(nn.Linear(dim, dim // 16), nn.ReLU(), nn.Linear(dim // 16, dim), nn.Sigmoid())
+        self.classifier = nn.Sequential(nn.LayerNorm(dim), nn.Dropout(0.3), nn.Linear(dim, dim // 2), nn.GELU(),
+                                        nn.Dropout(0.2), nn.Linear(dim // 2, dim // 4), nn.GELU(),
+                                        nn.Linear(dim // 4, 1))
+
+    def forward(self, pooled):
+        f = l2_normalize(pooled, eps=1e-6)
+        return self.classifier(f * self.se(f)).squeeze(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fusion / calibration  (train_fusion_head_only.py:230-317, appv3.py:1497-1510,1573-1578,3147-3182, coral.py:300-322)
+# ---------------------------------------------------------------------------------------------------------
+class TemperatureScaler(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.T = nn.Parameter(torch.tensor(1.0))
+
+    def forward(self, logits):
+        return logits / (self.T + 1e-6)
+
+
+class AdaptiveFusionHead(nn.Module):
+    """w = softmax(MLP([zf, zs, |zf − zs|])); z = (w0·zf + w1·zs) / (T + 1e-6)."""
+
+    def __init__(self, hidden_dim: int = 32):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(3, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, 2))
+        self.temp = TemperatureScaler()
+
+    def forward(self, z_freq, z_sig):
+        w = F.softmax(self.mlp(torch.stack([z_freq, z_sig, (z_freq - z_sig).abs()], dim=-1)), dim=-1)
+        return self.temp(w[..., 0] * z_freq + w[..., 1] * z_sig)
+
+
+class LinearFusionHead(nn.Module):
+    """The shipped 2→1 `FusionHead` (appv3.py:1573-1578; `siglip/fusion_head.safetensors`)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc = nn.Linear(2, 1)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class _FeatureNormalizer(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.register_buffer("mean", torch.zeros(dim))
+        self.register_buffer("std", torch.ones(dim))
+
+    def forward(self, x):
+        return (x - self.mean) / (self.std + 1e-6)
+
+
+class _ContrastScaler(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(dim))
+        self.beta = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return torch.tanh(self.alpha * x + self.beta)
+
+
+class _BandGating(nn.Module):
+    def __init__(self, dim, num_bands=4):
+        super().__init__()
+        assert dim % num_bands == 0
+        self.band_dim, self.num_bands = dim // num_bands, num_bands
+        self.gates = nn.Parameter(torch.zeros(num_bands))
+
+    def forward(self, x):
+        g = torch.sigmoid(self.gates).repeat_interleave(self.band_dim)
+        return x * g
+
+
+class _ResidualMLPBlock(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return x + self.fc2(F.gelu(self.fc1(self.norm(x))))
+
+
+class FreqMLPv5(nn.Module):
+    """v5 frequency-feature classifier (train_fusion_head_only.py:282-301)."""
+
+    def __init__(self, dim: int = 24, hidden: int = 64, num_bands: int = 4):
+        super().__init__()
+        self.normer = _FeatureNormalizer(dim)
+        self.contrast = _ContrastScaler(dim)
+        self.band = _BandGating(dim, num_bands)
+        self.blocks = nn.ModuleList([_ResidualMLPBlock(dim, hidden), _ResidualMLPBlock(dim, hidden)])
+        self.head = nn.Linear(dim, 1)
+        self.temp = TemperatureScaler()
+
+    def forward(self, x):
+        x = self.band(self.contrast(self.normer(x)))
+        for blk in self.blocks:
+            x = blk(x)
+        return self.temp(self.head(x).squeeze(-1))
+
+
+class _SafeLayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(dim=-1, keepdim=True)
+        var = x.var(dim=-1, unbiased=False, keepdim=True)
+        return (x - mean) / torch.sqrt(var + self.eps) * self.weight + self.bias
+
+
+class FreqMLPApp(nn.Module):
+    """The shipped app FreqMLP (appv3.py:1497-1510; `siglip/freq_mlp.safetensors`: net.0 LN(24), net.1 24→64,
+    net.3 64→1).  The reference adds 0.001·randn jitter in eval mode (:1508-1509); `jitter=False` gives the
+    deterministic function used for the known-answer test."""
+
+    def __init__(self, in_dim: int = 24, hid: int = 64):
+        super().__init__()
+        self.net = nn.Sequential(_SafeLayerNorm(in_dim), nn.Linear(in_dim, hid), nn.GELU(), nn.Linear(hid, 1))
+
+    def forward(self, x, jitter: bool = False):
+        if jitter and not self.training:
+            x = x + 0.001 * torch.randn_like(x)
+        return self.net(x).squeeze(-1)
+
+
+def _logit(p: float) -> float:
+    p = min(max(p, 1e-6), 1 - 1e-6)
+    return math.log(p / (1 - p))
+
+
+class CoralCalibrator:
+    """Ordinal 5-bin calibration (appv3.py:3154-3182): g_k = σ(z − c_k); p0 = 1−g0, p_k = g_{k−1}−g_k, p4 = g3."""
+
+    def __init__(self, cutpoints: Optional[dict] = None, logit_cuts: Optional[Sequence[float]] = None):
+        if logit_cuts is not None:
+            cuts = list(logit_cuts)
+        elif cutpoints:
+            cuts = [_logit(cutpoints[k]) for k in ("q25", "q50", "q75", "max")]
+        else:
+            cuts = [_logit(0.32), _logit(0.47), _logit(0.61), _logit(0.75)]
+        self.c = torch.tensor(cuts, dtype=torch.float32)
+
+    @torch.no_grad()
+    def probs(self, z_scaled):
+        g = torch.sigmoid(torch.as_tensor(z_scaled, dtype=torch.float32) - self.c)
+        p = torch.cat([1.0 - g[:1], g[:-1] - g[1:], g[-1:]])
+        return p / (p.sum() + 1e-8)
+
+    @torch.no_grad()
+    def predict(self, z_scaled):
+        p = self.probs(z_scaled)
+        return int(torch.argmax(p).item()), p
+
+    @torch.no_grad()
+    def probs_batch(self, z_scaled: torch.Tensor) -> torch.Tensor:
+        """Vectorised over a batch of fused logits (the app's 9-crop + rotated-view pattern, appv3.py:3221-3247)."""
+        g = torch.sigmoid(z_scaled.float().unsqueeze(-1) - self.c.to(z_scaled.device))
+        p = torch.cat([1.0 - g[..., :1], g[..., :-1] - g[..., 1:], g[..., -1:]], dim=-1)
+        return p / (p.sum(dim=-1, keepdim=True) + 1e-8)
+
+
+RISK_NAMES = ["REAL", "LEAN_REAL", "BORDERLINE", "LEAN_FAKE", "FAKE"]
+
+
+def fit_coral_cutpoints(logits: torch.Tensor, labels: torch.Tensor = None, num_classes: int = 5) -> List[float]:
+    """15/35/55/75-percentile cut-points of the fused logits (coral.py:300-322: value at index int(q·n) of the
+    ascending sort)."""
+    s = np.sort(np.asarray(logits.detach().cpu().numpy() if torch.is_tensor(logits) else logits))
+    return [float(s[int(q * len(s))]) for q in (0.15, 0.35, 0.55, 0.75)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses / metrics  (Siglip2sidafrozen.py:69-189, cifake_binary_classifier.py:238-251,788-792)
+# ---------------------------------------------------------------------------------------------------------
+def focal_loss(logits, targets, alpha: float = 0.25, gamma: float = 2.0):
+    p = torch.sigmoid(logits)
+    ce = F.binary_cross_entropy_with_logits(logits, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    alpha_t = alpha * targets + (1 - alpha) * (1 - targets)
+    return (alpha_t * (1 - p_t) ** gamma * ce).mean()
+
+
+def _box(x, k):
+    return F.conv2d(x, torch.ones(1, 1, k, k, device=x.device, dtype=x.dtype), padding=k // 2)
+
+
+def boundary_aware_loss(logits, targets, kernel_size: int = 3):
+    """Convolution-morphology branch of the reference (Siglip2sidafrozen.py:107-115), the one taken when kornia
+    is absent: boundary = dilate − erode by a k×k box; BCE weighted 1 + 3·boundary."""
+    s = _box(targets, kernel_size)
+    boundary = ((s > 0).float() - (s == kernel_size ** 2).float()).detach()
+    bce = F.binary_cross_entropy_with_logits(logits, targets, reduction="none")
+    return (bce * (1 + 3 * boundary)).mean()
+
+
+def morphological_loss(logits, targets, kernel_size: int = 3):
+    """Smoothness-penalty fallback branch (Siglip2sidafrozen.py:136-140)."""
+    p = torch.sigmoid(logits)
+    return (p[:, :, :, 1:] - p[:, :, :, :-1]).abs().mean() + (p[:, :, 1:, :] - p[:, :, :-1, :]).abs().mean()
+
+
+def iou_loss(logits, targets, smooth: float = 1e-6):
+    p = torch.sigmoid(logits)
+    inter = (p * targets).sum(dim=(1, 2, 3))
+    union = p.sum(dim=(1, 2, 3)) + targets.sum(dim=(1, 2, 3)) - inter + smooth
+    return 1 - (inter / union).mean()
+
+
+def _dice_term(logits, targets, eps):
+    p = torch.sigmoid(logits)
+    inter = (p * targets).sum(dim=(1, 2, 3))
+    denom = p.sum(dim=(1, 2, 3)) + targets.sum(dim=(1, 2, 3)) + eps
+    return 1 - (2 * inter / denom).mean()
+
+
+def bce_dice_loss(logits, targets, bce_w: float = 1.0, dice_w: float = 0.5, eps: float = 1e-6):
+    return bce_w * F.binary_cross_entropy_with_logits(logits, targets) + dice_w * _dice_term(logits, targets, eps)
+
+
+def combined_segmentation_loss(logits, targets, bce_w=0.4, focal_w=0.3, dice_w=0.5, boundary_w=0.4, iou_w=0.4,
+                               morph_w=0.2, eps=1e-6):
+    return (bce_w * F.binary_cross_entropy_with_logits(logits, targets) + focal_w * focal_loss(logits, targets)
+            + dice_w * _dice_term(logits, targets, eps) + boundary_w * boundary_aware_loss(logits, targets)
+            + iou_w * iou_loss(logits, targets) + morph_w * morphological_loss(logits, targets))
+
+
+def dice_iou_from_logits(logits, targets, thr: float = 0.5, eps: float = 1e-6):
+    p_bin = (torch.sigmoid(logits) > thr).float()
+    inter = (p_bin * targets).sum(dim=(1, 2, 3))
+    union = (p_bin + targets - p_bin * targets).sum(dim=(1, 2, 3)) + eps
+    dice = 2 * inter / (p_bin.sum(dim=(1, 2, 3)) + targets.sum(dim=(1, 2, 3)) + eps)
+    return dice.detach().cpu().tolist(), (inter / union).detach().cpu().tolist(), p_bin
+
+
+class FocalLoss(nn.Module):
+    """cifake_binary_classifier.py:238-251 (pt = exp(−bce) form)."""
+
+    def __init__(self, alpha: float = 1.0, gamma: float = 2.0, pos_weight=None):
+        super().__init__()
+        self.alpha, self.gamma, self.pos_weight = alpha, gamma, pos_weight
+
+    def forward(self, inputs, targets):
+        bce = F.binary_cross_entropy_with_logits(inputs, targets, pos_weight=self.pos_weight, reduction="none")
+        return (self.alpha * (1 - torch.exp(-bce)) ** self.gamma * bce).mean()
+
+
+def label_smoothing_loss(pred, target, smoothing: float = 0.1):
+    target = target.float() * (1 - smoothing) + 0.5 * smoothing
+    return F.binary_cross_entropy_with_logits(pred, target)
+
+
+def mtl_loss(cls_logit, seg_logits, y_class, masks, has_mask, lam_seg: float = 1.0, enhanced: bool = False):
+    """Train-step loss of the SID script (Siglip2sidafrozen.py:1377-1389): CE + λ·seg-loss on the samples that
+    carry a mask."""
+    loss = F.cross_entropy(cls_logit, y_class)
+    if has_mask.any():
+        seg = combined_segmentation_loss if enhanced else bce_dice_loss
+        loss = loss + lam_seg * seg(seg_logits[has_mask], masks[has_mask])
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------------------
+# composed task models (reference L3 modules: encoder surface O + head)
+# ---------------------------------------------------------------------------------------------------------
+class FastBinaryClassifierHIP(nn.Module):
+    """`FastBinaryClassifier.forward` (cifake_binary_classifier.py:714-749) on the HIP encoder: bilinear resize to
+    the model resolution if needed → `backbone.encode_image` → head."""
+
+    def __init__(self, backbone: nn.Module, model_size: str = "small", dropout_rate: float = 0.1,
+                 use_lightweight_attention: bool = True):
+        super().__init__()
+        self.backbone = backbone
+        self.resolution = backbone.image_size
+        self.feature_dim = backbone.embed_dim
+        self.head = CifakeBinaryHead(self.feature_dim, model_size, dropout_rate, use_lightweight_attention)
+
+    def forward(self, x, return_features: bool = False):
+        if x.shape[-1] != self.resolution:
+            x = F.interpolate(x, size=(self.resolution, self.resolution), mode="bilinear", align_corners=False)
+        return self.head(self.backbone.encode_image(x), return_features)
+
+
+class BinaryVideoClassifierHIP(nn.Module):
+    """`BinaryVideoClassifier.forward` (hidf_video_classifier.py:299-320): (B,T,C,H,W) → per-frame encoder →
+    L2-norm → temporal mean → MLP → (B,) logits."""
+
+    def __init__(self, vision_encoder: nn.Module, num_frames: int = 4, dropout_rate: float = 0.3):
+        super().__init__()
+        self.vision_encoder = vision_encoder
+        self.feature_dim = vision_encoder.embed_dim
+        self.num_frames = num_frames
+        self.head = VideoBinaryHead(self.feature_dim, num_frames, dropout_rate)
+
+    def forward(self, x):
+        b, t, c, h, w = x.shape
+        return self.head(self.vision_encoder.encode_image(x.view(b * t, c, h, w)), batch_size=b)
+
+
+class SEBinaryClassifierHIP(nn.Module):
+    """`BinaryClassifier.forward` of the fusion script (train_fusion_head_only.py:101-109): frozen encoder under
+    no_grad, nearest-neighbour resize to the model size, SE gate + MLP."""
+
+    def __init__(self, backbone: nn.Module):
+        super().__init__()
+        self.backbone = backbone
+        self.img_size = backbone.image_size
+        self.head = SEBinaryHead(backbone.embed_dim)
+
+    def forward(self, x):
+        with torch.no_grad():
+            if x.shape[-1] != self.img_size:
+                x = F.interpolate(x, size=(self.img_size, self.img_size))
+            f = self.backbone.encode_image(x)
+        return self.head(f)

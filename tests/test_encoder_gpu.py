@@ -164,3 +164,63 @@ def test_open_clip_surface(pkg, hiplib):
     assert torch.equal(f, ref.detach())
     names = [n for n, _ in model.named_parameters()]
     assert any("layers.2" in n for n in names)
+
+
+def test_sid_multitask_model_vs_cpu_composition(pkg, oracle, hiplib):
+    """Row a1 (SigLIP2_MTL.forward): HIP encoder + decoder/cls head on the GPU against the CPU composition of the
+    HF-pinned oracle encoder and the reference-pinned heads (tests/test_heads.py), forward and backward."""
+    import copy
+    H = pkg.heads
+    cfg = pkg.get_config("hostile")
+    sd = pkg.weights.seeded_state_dict(cfg, seed=13)
+    enc = pkg.SiglipVisionModelHIP(cfg, compute_dtype="fp32")
+    enc.load_state_dict(sd)
+    torch.manual_seed(0)
+    model = H.SigLIP2MTL(enc, seg_layers=(0, 1, -1), embed_dim=32, freeze_below=1)
+    heads_cpu = copy.deepcopy({"cls": model.cls_head, "dec": model.decoder})
+    model = model.to("cuda")
+    x = pkg.weights.seeded_pixels(2, 56, 56, seed=17)
+    y = torch.tensor([2, 0])
+    masks = (pkg.weights.seeded_tensor("masks", (2, 1, 56, 56), 1.0) > 0.2).float()
+    has_mask = torch.tensor([True, True])
+    cls_logit, seg_logits = model(x.cuda())
+    assert cls_logit.shape == (2, 3) and seg_logits.shape == (2, 1, 56, 56)
+    loss = H.mtl_loss(cls_logit, seg_logits, y.cuda(), masks.cuda(), has_mask.cuda(), lam_seg=1.0)
+    loss.backward()
+    # CPU composition
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = oracle.vision_forward(x, sdr, cfg, True, True)
+    cls_ref = heads_cpu["cls"](ref["pooler_output"])
+    feats = [ref["hidden_states"][i] for i in (1, 2, cfg.num_hidden_layers)]
+    seg_ref = heads_cpu["dec"](feats, (4, 4), target_size=56)
+    loss_ref = H.mtl_loss(cls_ref, seg_ref, y, masks, has_mask, lam_seg=1.0)
+    loss_ref.backward()
+    assert (cls_logit.cpu() - cls_ref).abs().max().item() < 1e-3       # north-star logit bound
+    assert (seg_logits.cpu() - seg_ref).abs().max().item() < 1e-3
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    named = dict(model.encoder.named_parameters())
+    assert named["encoder.layers.0.mlp.fc1.weight"].grad is None          # frozen prefix
+    for k in ["encoder.layers.1.mlp.fc2.weight", "encoder.layers.1.self_attn.v_proj.weight", "head.mlp.fc1.weight"]:
+        g, r = named[k].grad.cpu(), sdr[k].grad
+        assert (g - r).abs().max().item() <= 1e-3 * r.abs().max().item() + 1e-7, k
+    gd = model.decoder.projs[0].proj.weight.grad.cpu()
+    rd = heads_cpu["dec"].projs[0].proj.weight.grad
+    assert (gd - rd).abs().max().item() <= 1e-3 * rd.abs().max().item() + 1e-7
+
+
+def test_binary_and_video_models_run_on_hip_encoder(pkg, hiplib):
+    H = pkg.heads
+    bb, _, _ = pkg.create_model_and_transforms("tiny", device="cuda", compute_dtype="bf16")
+    clf = H.FastBinaryClassifierHIP(bb, model_size="small").cuda()
+    x = pkg.weights.seeded_pixels(3, 40, 40, seed=2).cuda()          # resized to the model's 32x32
+    logits = clf(x)
+    assert logits.shape == (3,)
+    torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.tensor([1., 0., 1.]).cuda()).backward()
+    assert bb.visual.encoder.layers[0].mlp.fc1.weight.grad is not None
+    vid = H.BinaryVideoClassifierHIP(bb, num_frames=4).cuda().eval()   # eval: dropout off, deterministic
+    clips = pkg.weights.seeded_pixels(2 * 4, 32, 32, seed=3).view(2, 4, 3, 32, 32).cuda()
+    assert vid(clips).shape == (2,)
+    # frames of one clip are independent images: the clip logit equals the head applied to per-frame features
+    with torch.no_grad():
+        f = bb.encode_image(clips.view(8, 3, 32, 32))
+        assert torch.allclose(vid(clips), vid.head(f, batch_size=2), atol=1e-6)

@@ -1,0 +1,137 @@
+"""CPU: this repo's heads / decoder / losses / calibration against golden vectors produced by EXECUTING the
+reference's own class definitions (oracle/gen_golden_heads.py) and against the data files the reference ships
+(siglip/fusion_head.safetensors, freq_mlp.safetensors, coral_*.json — copied as fixtures to tests/golden/ref_siglip)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+REC = dict(np.load(os.path.join(gu.GOLDEN_DIR, "heads.npz")))
+REF_SIGLIP = os.path.join(gu.GOLDEN_DIR, "ref_siglip")
+
+
+def seed_module(pkg, mod, prefix, seed=0):
+    """Same naming rule as oracle/gen_golden_heads.py::seed_module."""
+    W = pkg.weights
+    with torch.no_grad():
+        for name, p in list(mod.named_parameters()) + list(mod.named_buffers()):
+            full = prefix + name
+            if p.dim() >= 2:
+                t = W.seeded_tensor(full, p.shape, math.sqrt(3.0 / int(np.prod(p.shape[1:]))), seed)
+            elif name.endswith("std"):
+                t = W.seeded_tensor(full, p.shape, 0.3, seed, 1.0)
+            elif name.endswith("weight") or name.endswith("alpha") or name.endswith("T"):
+                t = W.seeded_tensor(full, p.shape, 0.2, seed, 1.0)
+            else:
+                t = W.seeded_tensor(full, p.shape, 0.2, seed)
+            p.copy_(t.reshape(p.shape))
+
+
+def T(pkg, name, shape, bound=1.0, seed=0, offset=0.0):
+    return pkg.weights.seeded_tensor(name, shape, bound, seed, offset)
+
+
+def close(got, ref, tol=2e-5):
+    got = np.asarray(got.detach().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref).max()
+    assert err <= tol * max(1.0, np.abs(ref).max()), f"max|err| {err:.3e}"
+
+
+def test_mask_decoder_matches_reference(pkg):
+    B, g, D, E, K, S = (int(v) for v in REC["decoder.meta"])
+    H = pkg.heads
+    taps = [T(pkg, f"tap{i}", (B, g * g, D)) for i in range(K)]
+    for early_head in (False, True):   # reference order, and the HBM-saving head-before-upsample order
+        dec = H.SegFormerMaskDecoder([D] * K, embed_dim=E, head_before_upsample=early_head).eval()
+        seed_module(pkg, dec, "decoder.")
+        close(dec(taps, (g, g), target_size=S), REC["decoder.out"], 5e-6 if not early_head else 2e-5)
+
+
+def test_segmentation_losses_match_reference(pkg):
+    H = pkg.heads
+    logits = T(pkg, "seg_logits", (3, 1, 24, 24), 3.0)
+    targets = (T(pkg, "seg_targets", (3, 1, 24, 24)) > 0.3).float()
+    for fn in ["focal_loss", "boundary_aware_loss", "morphological_loss", "iou_loss", "combined_segmentation_loss",
+               "bce_dice_loss"]:
+        close(getattr(H, fn)(logits, targets), REC["loss." + fn], 1e-6)
+    dice, iou, pbin = H.dice_iou_from_logits(logits, targets)
+    close(np.asarray(dice), REC["loss.dice"], 1e-6)
+    close(np.asarray(iou), REC["loss.iou"], 1e-6)
+    assert float(pbin.sum()) == float(REC["loss.pbin_sum"])
+    y = (T(pkg, "bin_targets", (16,)) > 0).float()
+    z = T(pkg, "bin_logits", (16,), 3.0)
+    close(H.FocalLoss(1.0, 2.0)(z, y), REC["loss.FocalLoss"], 1e-6)
+    close(H.FocalLoss(0.5, 1.5, pos_weight=torch.tensor(2.0))(z, y), REC["loss.FocalLoss_pw"], 1e-6)
+    close(H.label_smoothing_loss(z, y, 0.1), REC["loss.label_smoothing"], 1e-6)
+
+
+@pytest.mark.parametrize("size", ["tiny", "small", "medium", "large"])
+def test_cifake_head_matches_reference(pkg, size):
+    dim = 128 if size == "large" else 64
+    head = pkg.heads.CifakeBinaryHead(dim, model_size=size).eval()
+    seed_module(pkg, head, f"cifake.{size}.")
+    feats = T(pkg, "cifake_features_large" if size == "large" else "cifake_features", (4, dim), 2.0)
+    close(head(feats), REC[f"cifake.{size}.logits"])
+
+
+def test_video_and_se_heads_match_reference(pkg):
+    vid = pkg.heads.VideoBinaryHead(64, num_frames=4).eval()
+    seed_module(pkg, vid, "video.")
+    close(vid(T(pkg, "video_features", (12, 64), 2.0), batch_size=3), REC["video.logits"])
+    dim = int(REC["se.dim"])
+    se = pkg.heads.SEBinaryHead(dim).eval()
+    seed_module(pkg, se, "se.")
+    close(se(T(pkg, "se_features", (3, dim), 2.0)), REC["se.logits"])
+
+
+def test_fusion_and_freq_match_reference(pkg):
+    H = pkg.heads
+    fm = H.FreqMLPv5().eval()
+    seed_module(pkg, fm, "freqv5.")
+    close(fm(T(pkg, "freq_in", (5, 24), 2.0)), REC["freqv5.logits"])
+    af = H.AdaptiveFusionHead().eval()
+    seed_module(pkg, af, "afusion.")
+    close(af(T(pkg, "zf", (7,), 3.0), T(pkg, "zs", (7,), 3.0)), REC["afusion.z"])
+    close(np.asarray(H.fit_coral_cutpoints(T(pkg, "coral_fit_logits", (257,), 4.0))), REC["coral.fit_cuts"], 1e-7)
+
+
+def test_shipped_artifacts_known_answers(pkg):
+    """The weights / calibration files the reference ships, run through this repo's modules."""
+    from safetensors.torch import load_file
+    H = pkg.heads
+    fh = H.LinearFusionHead()
+    fh.load_state_dict(load_file(os.path.join(REF_SIGLIP, "fusion_head.safetensors")))
+    close(fh(T(pkg, "fusion_probs", (6, 2), 0.5, 0, 0.5)), REC["shipped.fusion_out"], 1e-6)
+    fa = H.FreqMLPApp()
+    fa.load_state_dict(load_file(os.path.join(REF_SIGLIP, "freq_mlp.safetensors")))
+    close(fa(T(pkg, "freq_in", (5, 24), 2.0)), REC["shipped.freq_out"], 1e-5)
+    cuts = json.load(open(os.path.join(REF_SIGLIP, "coral_cutpoints.json")))
+    cc = H.CoralCalibrator(cuts)
+    close(cc.c, REC["shipped.coral_c"], 1e-6)
+    zs = REC["shipped.coral_z"]
+    got = np.stack([cc.probs(float(z)).numpy() for z in zs])
+    close(got, REC["shipped.coral_probs"], 1e-6)
+    assert [cc.predict(float(z))[0] for z in zs] == [int(i) for i in REC["shipped.coral_idx"]]
+    close(cc.probs_batch(torch.tensor(zs, dtype=torch.float32)), REC["shipped.coral_probs"], 1e-6)
+    temp = json.load(open(os.path.join(REF_SIGLIP, "coral_temp.json")))["temperature"]
+    assert abs(temp - float(REC["shipped.coral_temp"])) < 1e-12 and len(H.RISK_NAMES) == 5
+
+
+def test_mtl_loss_and_shapes(pkg):
+    H = pkg.heads
+    cls = T(pkg, "cls", (4, 3), 2.0)
+    seg = T(pkg, "seg", (4, 1, 16, 16), 2.0)
+    y = torch.tensor([0, 1, 2, 1])
+    m = (T(pkg, "m", (4, 1, 16, 16)) > 0).float()
+    hm = torch.tensor([True, False, True, True])
+    base = torch.nn.functional.cross_entropy(cls, y)
+    assert torch.allclose(H.mtl_loss(cls, seg, y, m, torch.zeros(4, dtype=torch.bool)), base)
+    full = H.mtl_loss(cls, seg, y, m, hm, lam_seg=0.7)
+    assert torch.allclose(full, base + 0.7 * H.bce_dice_loss(seg[hm], m[hm]))
