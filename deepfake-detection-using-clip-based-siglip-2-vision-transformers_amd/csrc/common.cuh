@@ -93,21 +93,24 @@ template <> struct Vec<bf16, 8> {
 };
 
 // ---- GELU (tanh form, 'gelu_pytorch_tanh') and its derivative ---------------------------------------
-__device__ __forceinline__ float tanh_fast(float z) {
-  // tanh(z) = 1 - 2/(exp(2z)+1); saturates cleanly for |z| large
-  float e = __expf(2.0f * z);
-  return 1.0f - 2.0f / (e + 1.0f);
+// 0.5 x (1 + tanh(z)) == x * sigmoid(2z),  z = c (x + a x^3).  Written with one v_exp_f32 and one v_rcp_f32 (both
+// hardware transcendentals, ~1 ulp) and no IEEE division, because these run in GEMM epilogues where VALU time is
+// exposed.  sigmoid(2z) = 1 / (1 + exp2(w)),  w = -2z*log2(e) = x * (k1 + k2 x^2); saturates to 0 / 1 without NaNs.
+#define SGL_GELU_C 0.7978845608028654f
+#define SGL_GELU_A 0.044715f
+#define SGL_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float gelu_sigmoid(float x, float x2) {
+  const float k1 = -2.0f * SGL_GELU_C * SGL_LOG2E, k2 = -2.0f * SGL_GELU_C * SGL_GELU_A * SGL_LOG2E;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(k2, x2, k1));
+  return __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ float gelu_tanh(float x) {
-  const float c = 0.7978845608028654f;
-  float t = tanh_fast(c * (x + 0.044715f * x * x * x));
-  return 0.5f * x * (1.0f + t);
-}
+__device__ __forceinline__ float gelu_tanh(float x) { return x * gelu_sigmoid(x, x * x); }
+// d/dx [x s(2z)] = s + x s (1 - s) (2z)',   (2z)' = 2c (1 + 3 a x^2)
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
-  const float c = 0.7978845608028654f;
-  float x2 = x * x;
-  float t = tanh_fast(c * (x + 0.044715f * x * x2));
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x2);
+  const float x2 = x * x;
+  const float s = gelu_sigmoid(x, x2);
+  const float zp = fmaf(6.0f * SGL_GELU_C * SGL_GELU_A, x2, 2.0f * SGL_GELU_C);
+  return fmaf(x * (s * (1.0f - s)), zp, s);
 }
 
 // ---- buffer resources (hardware bounds check: out-of-range loads return 0, stores are dropped) -------

@@ -15,8 +15,10 @@
 //   tn2 image [64 m][256 n]      512-B rows: slot s of row m holds source chunk s ^ (2*(m&3) + 8*((m>>3)&1))
 // Wave w -> (wr, wc) = ((w>>1)&1, (w&1) + 2*(w>>2)) so that the two waves sharing a SIMD (w, w+4) sit in different
 // column halves: a half-empty last column tile (N = 1152 = 4.5 tiles) then costs half a tile, not a whole one.
-// blockIdx -> tile is XCD-aware: the 8 XCDs (round-robin over blockIdx) each own the row panels tile_m ≡ xcd (mod 8),
-// so an A panel is fetched into one L2 only.  Placement affects speed only.
+// blockIdx -> tile is XCD-aware (unit_of_block / tile_of_unit below): each XCD works through a contiguous chunk of
+// a grouped tile order, so its concurrent workgroups share A and B panels in its private L2.  Measured with
+// rocprofv3 FETCH_SIZE on the fc1 shape: the earlier "row panel per XCD" map fetched 6x the algorithmic bytes
+// because the 10 MB weight panel thrashed every 4 MiB L2.  Placement affects speed only.
 #include "common.cuh"
 #include "epilogue.cuh"
 #include "kernels.h"
@@ -131,10 +133,19 @@ __device__ __forceinline__ void sched_pipeline() {
   sched_step<READS, 12>(); sched_step<READS, 13>(); sched_step<READS, 14>(); sched_step<READS, 15>();
 }
 
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
-  const int xcd = bid & 7, local = bid >> 3;
-  tile_n = local % tiles_n;
-  tile_m = (local / tiles_n) * 8 + xcd;
+// blockIdx -> work unit.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the XCD group), each
+// with a private 4 MiB L2.  XCD x takes the CONTIGUOUS chunk [x*per, (x+1)*per) of a locality-ordered unit list, so
+// the ~32 workgroups it runs at any moment are neighbours in that list.  Speed only; any placement is correct.
+__device__ __forceinline__ int unit_of_block(int bid, int per) { return (bid & 7) * per + (bid >> 3); }
+
+// NT tile order: bands of 8 row-tiles, column-major inside a band ("grouped" order): 32 consecutive tiles form an
+// 8 x 4 block of the tile grid, i.e. 8 A panels + 4 B panels feed 32 tiles out of one L2.
+__device__ __forceinline__ void tile_of_unit(int u, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+  const int band = u / (8 * tiles_n);
+  const int rows = (tiles_m - band * 8 < 8) ? tiles_m - band * 8 : 8;
+  const int r = u - band * 8 * tiles_n;
+  tile_n = r / rows;
+  tile_m = band * 8 + (r - tile_n * rows);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -143,9 +154,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ B, int ldb, int M, int N, int K,
                                                           int tiles_m, int tiles_n, EpiParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = tiles_m * tiles_n;
+  const int unit = unit_of_block(blockIdx.x, (ntiles + 7) >> 3);
+  if (unit >= ntiles) return;  // whole block exits together
   int tile_m, tile_n;
-  tile_of_block(blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
-  if (tile_m >= tiles_m) return;  // whole block exits together
+  tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2);
@@ -227,14 +240,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict__ A, int lda,
                                                           const bf16* __restrict__ B, int ldb, int Mred, int N1, int N2,
-                                                          int m_per_split, int tiles_1, int tiles_2, EpiParams p) {
+                                                          int m_per_split, int nsplits, int tiles_1, int tiles_2,
+                                                          EpiParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tile1 = blockIdx.x / tiles_2, tile2 = blockIdx.x - tile1 * tiles_2;
+  // units ordered (split, tile1, tile2): an XCD's contiguous chunk shares one token range and neighbouring panels
+  const int ntiles = tiles_1 * tiles_2;
+  const int nunits = ntiles * nsplits;
+  const int unit = unit_of_block(blockIdx.x, (nunits + 7) >> 3);
+  if (unit >= nunits) return;
+  const int split = unit / ntiles, trem = unit - split * ntiles;
+  const int tile1 = trem / tiles_2, tile2 = trem - tile1 * tiles_2;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2);
   const int n1_0 = tile1 * T_BM, n2_0 = tile2 * T_BN;
-  const int m_begin = blockIdx.y * m_per_split;
+  const int m_begin = split * m_per_split;
   const int m_end = (m_begin + m_per_split < Mred) ? m_begin + m_per_split : Mred;
   const int rows = m_end - m_begin;
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(A + (size_t)m_begin * lda, (uint32_t)((size_t)rows * lda * 2));
@@ -320,7 +340,7 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
     attr = true;
   }
   const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + T_BN - 1) / T_BN;
-  const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+  const int grid = ((tiles_m * tiles_n + 7) / 8) * 8;
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
                      tiles_n, p);
   return hipGetLastError();
@@ -354,9 +374,9 @@ hipError_t gemm_tn2_bf16(const void* A_, int lda, const void* B_, int ldb, int M
     attr = true;
   }
   const int tiles_1 = (N1 + T_BM - 1) / T_BM, tiles_2 = (N2 + T_BN - 1) / T_BN;
-  const int grid = tiles_1 * tiles_2;
-  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid, splits), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_,
-                     ldb, Mred, N1, N2, m_per, tiles_1, tiles_2, p);
+  const int grid = ((tiles_1 * tiles_2 * splits + 7) / 8) * 8;
+  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
+                     Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
   return hipGetLastError();
 }
 

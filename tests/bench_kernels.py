@@ -34,7 +34,24 @@ def tn(Mr, N1, N2):
     # splits=0 -> library default is chosen by the encoder host code; here emulate it
     t = timeit(f); return t, 2.0 * Mr * N1 * N2 / t / 1e12
 
+def nt_epi(Mm, N, K, epi):
+    A = torch.randn(Mm, K, device="cuda").bfloat16(); Bw = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    f32 = epi == 2
+    out = torch.empty(Mm, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+    out2 = torch.empty(Mm, N, device="cuda", dtype=torch.bfloat16) if epi == 1 else None
+    res = torch.randn(Mm, N, device="cuda") if epi == 2 else None
+    aux = torch.randn(Mm, N, device="cuda").bfloat16() if epi == 4 else None
+    def f():
+        assert lib.sgl_op_gemm_nt(1, A.data_ptr(), K, Bw.data_ptr(), K, Mm, N, K, epi, out.data_ptr(), N,
+                                  None if out2 is None else out2.data_ptr(), N, bias.data_ptr(),
+                                  None if res is None else res.data_ptr(), N, None if aux is None else aux.data_ptr(), N,
+                                  None, 1, 1, 1, 8, 8, 1, st.cuda_stream) == 0
+    t = timeit(f); return t, 2.0 * Mm * N * K / t / 1e12
+
 print(f"gen={os.environ.get('SGL_GEMM_GEN','2')} B={B} M={M}")
+for name, (Mm, N, K, epi) in {"fc1+gelu": (M, Ip, D, 1), "gelu_bwd": (M, Ip, D, 4), "out+res": (M, D, D, 2), "fc2+res": (M, D, Ip, 2)}.items():
+    t, tf = nt_epi(Mm, N, K, epi); print(f"NT {name:8s} M={Mm:6d} N={N:5d} K={K:5d}  {t*1e3:8.3f} ms  {tf:7.1f} TF/s")
 for name, (Mm, N, K) in {"qkv": (M, 3*D, D), "out": (M, D, D), "fc1": (M, Ip, D), "fc2": (M, D, Ip), "dX_qkv": (M, D, 3*D),
                          "sq4096": (4096, 4096, 4096), "sq8192": (8192, 8192, 8192)}.items():
     t, tf = nt(Mm, N, K); print(f"NT {name:8s} M={Mm:6d} N={N:5d} K={K:5d}  {t*1e3:8.3f} ms  {tf:7.1f} TF/s")
