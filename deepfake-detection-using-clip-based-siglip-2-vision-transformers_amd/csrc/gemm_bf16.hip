@@ -313,7 +313,8 @@ hipError_t gemm_nt2_bf16(const void* A, int lda, const void* B, int ldb, int M, 
                          const EpiParams& p, hipStream_t s);
 hipError_t gemm_tn2_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int m_per,
                          int splits, const EpiParams& p, hipStream_t s);
-static int gemm_generation() {  // SGL_GEMM_GEN=1 forces the 128x128 register-staged kernels (A/B comparisons)
+// SGL_GEMM_GEN=1 forces the 128x128 register-staged kernels (A/B comparisons)
+static int gemm_generation() {
   static int gen = -1;
   if (gen < 0) {
     const char* e = getenv("SGL_GEMM_GEN");
@@ -344,7 +345,7 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if ((lda % 8) || (ldb % 8) || (K % 8) || K <= 0) return hipErrorInvalidValue;
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
-  if (gemm_generation() >= 2 && M >= 2048 && N >= 256)
+  if (gemm_generation() != 1 && M >= 2048 && N >= 256)
     return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
   const bf16* A = (const bf16*)A_;
   const bf16* B = (const bf16*)B_;
@@ -383,7 +384,7 @@ hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mr
       return hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
     return hipSuccess;
   }
-  if (gemm_generation() >= 2 && N1 >= 512 && N2 >= 512 && Mred >= 2048) {
+  if (gemm_generation() != 1 && N1 >= 512 && N2 >= 512 && Mred >= 2048) {
     // 256x256 tiles, one workgroup per CU: split the token reduction until ~256 workgroups exist
     // 256x256 tiles, one workgroup per CU (128 KiB LDS): keep tiles*splits <= 256 (a single full round)
     const int tiles = ((N1 + 255) / 256) * ((N2 + 255) / 256);

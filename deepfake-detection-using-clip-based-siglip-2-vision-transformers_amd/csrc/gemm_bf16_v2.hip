@@ -19,6 +19,8 @@
 // a grouped tile order, so its concurrent workgroups share A and B panels in its private L2.  Measured with
 // rocprofv3 FETCH_SIZE on the fc1 shape: the earlier "row panel per XCD" map fetched 6x the algorithmic bytes
 // because the 10 MB weight panel thrashed every 4 MiB L2.  Placement affects speed only.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "epilogue.cuh"
 #include "kernels.h"
@@ -49,9 +51,18 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
   float csum[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) csum[j] = 0.f;
+  // Barriers here only order LDS traffic, so they are raw s_barrier + lgkmcnt(0): __syncthreads() would also emit
+  // vmcnt(0) and make every pass wait for the previous pass's global stores to be acknowledged (microseconds under
+  // load, 8 times per tile).  The stores stay in flight across passes instead.
+#define SGL_LDS_BARRIER()                                  \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
-    __syncthreads();
+    if (pass == 0) __syncthreads(); else SGL_LDS_BARRIER();
     if (wr == (pass >> 1)) {
 #pragma unroll
       for (int i2 = 0; i2 < 4; ++i2)
@@ -61,7 +72,7 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
           for (int r = 0; r < 4; ++r)
             ct[(i2 * 16 + g * 4 + r) * T_CT_LD + wc * 64 + j * 16 + c16] = acc[4 * (pass & 1) + i2][j][r];
     }
-    __syncthreads();
+    SGL_LDS_BARRIER();
     const int mrow0 = m0 + pass * 64;
     if constexpr (EPI == EPI_F32) {
       if (p.atomic) {
@@ -101,11 +112,11 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
     // fused bias gradient: every thread always owns the same NV columns (512 % CPR == 0); fold the 512/CPR row
     // groups through LDS and add one value per column to p.colsum
     if (p.colsum) {
-      __syncthreads();
+      SGL_LDS_BARRIER();
       constexpr int GROUPS = 512 / CPR;
 #pragma unroll
       for (int j = 0; j < NV; ++j) ct[(t / CPR) * T_BN + (t % CPR) * NV + j] = csum[j];
-      __syncthreads();
+      SGL_LDS_BARRIER();
       if (t < T_BN && n0 + t < N) {
         float s = 0.f;
 #pragma unroll
