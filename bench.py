@@ -95,9 +95,16 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
         tot_f += fl
         del A, Bw, out, out2, res_t
     achieved = tot_f / tot_t / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if batch == 64 and os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch, measured offline
+        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "kernel": "sgl::gemm_nt2_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
-            "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None, "per_shape": per}
+            "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
+            "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                            "profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: 523.6 MB",
+            "per_shape": per}
 
 
 def host_cores() -> int:
@@ -207,7 +214,8 @@ def main():
     train_flops = cfg.train_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
 
     line = {
-        "metric": "images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16",
+        "metric": ("images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16" if args.config == "so400m-patch14-384"
+                   else f"images/sec (train fwd+bwd) {args.config}@{res} {args.mode}"),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.mode, "data": "synthetic",
