@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--kernel-reps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -105,6 +105,30 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
             "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                             "profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: 523.6 MB",
             "per_shape": per}
+
+
+def optimizer_step_roofline(pkg, model, x, reps=10):
+    """The step tail, reported beside the headline ('optimizer step reported separately'): fused
+    global-norm clip + AdamW over every encoder parameter (csrc/optimizer.hip), HIP-event timed on its stream.
+    Algorithmic bytes: 32 per parameter (norm pass reads g; update reads p,g,m,v and writes p,m,v)."""
+    out = model(pixel_values=x[:2], interpolate_pos_encoding=True)
+    out.pooler_output.square().mean().backward()
+    params = [p for p in model.parameters() if p.grad is not None]
+    opt = pkg.FusedAdamW(params, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
+    stream = torch.cuda.current_stream()
+    for _ in range(2):
+        opt.step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        opt.step()
+    e1.record(stream)
+    e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    n = sum(p.numel() for p in params)
+    return {"kernel": "sgl::grad_sqnorm_kernel + sgl::adamw_kernel (clip_grad_norm_ + AdamW.step, fp32)",
+            "params": n, "ms": round(t * 1e3, 3), "bound": "hbm", "achieved": round(32.0 * n / t / 1e9, 1),
+            "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(32.0 * n / t / PEAK_HBM, 4)}
 
 
 def host_cores() -> int:
@@ -230,6 +254,7 @@ def main():
               file=sys.stderr, flush=True)
         if world == 1:
             line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
+            line["optimizer_step"] = optimizer_step_roofline(pkg, model, x)
             del model
             torch.cuda.empty_cache()
             if not args.no_cpu_baseline:

@@ -47,6 +47,11 @@ class SglGrads(C.Structure):
                 [("accumulate", C.c_int)])
 
 
+class SglAdamwTensor(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("n", C.c_uint64), ("lr", C.c_float),
+                ("weight_decay", C.c_float)]
+
+
 _lib = None
 
 
@@ -107,6 +112,10 @@ def load():
     _sig(lib, "sgl_op_colsum", i, [i, _fp, i, i, i, _fp, i, _fp, sz, _fp])
     _sig(lib, "sgl_op_im2col", i, [_fp, i, _fp, i, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_pos_resize", i, [_fp, i, _fp, i, i, i, _fp])
+    i64 = C.c_int64
+    _sig(lib, "sgl_adamw_plan", i64, [C.POINTER(C.c_uint64), i, C.POINTER(C.c_int32), i64])
+    _sig(lib, "sgl_op_grad_norm", i, [_fp, _fp, i64, f, _fp, _fp, _fp])
+    _sig(lib, "sgl_op_adamw", i, [_fp, _fp, i64, C.c_double, C.c_double, C.c_double, i, _fp, _fp])
     _lib = lib
     return lib
 

@@ -175,6 +175,33 @@ int sgl_op_im2col(const float* pixels, int channels_last, void* out, int out_dty
                   sgl_stream stream);
 int sgl_op_pos_resize(const float* table, int native_grid, float* out, int gh, int gw, int D, sgl_stream stream);
 
+/* ---- optimizer step tail -----------------------------------------------------------------
+ * Replaces, for a list of fp32 tensors, the reference's per-step pair
+ *     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)   Siglip2sidafrozen.py:1396
+ *     torch.optim.AdamW(...).step()                                  Siglip2sidafrozen.py:1241-1244,1398
+ * without a host synchronisation: the clip coefficient stays in device memory.
+ * One table entry per parameter tensor; the table, the block map and the scratch live in DEVICE memory owned by the
+ * caller.  g == NULL marks a parameter without a gradient this step (skipped, as torch does). */
+typedef struct {
+  float* p;        /* fp32 parameter, updated in place */
+  const float* g;  /* fp32 gradient (not modified: the clip coefficient is applied on the fly) */
+  float* m;        /* exp_avg */
+  float* v;        /* exp_avg_sq */
+  uint64_t n;      /* elements */
+  float lr, weight_decay; /* of the parameter group the tensor belongs to */
+} sgl_adamw_tensor;
+/* HOST helper: cuts tensor t into ceil(numel[t]/4096) chunks and writes (tensor, chunk) int32 pairs into blockmap
+ * (host memory, capacity in pairs; may be NULL to size it).  Returns the number of pairs (= workgroups). */
+int64_t sgl_adamw_plan(const uint64_t* numel, int ntensors, int32_t* blockmap, int64_t capacity_pairs);
+/* norm_and_coef[0] = sqrt(sum g^2) over the table; [1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0).
+ * partials: nblocks floats of scratch.  Reduction order is fixed: bitwise reproducible. */
+int sgl_op_grad_norm(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, float max_norm,
+                     float* partials, float* norm_and_coef, sgl_stream stream);
+/* One AdamW step (decoupled weight decay, torch/optim/adamw.py operation order) on every tensor of the table;
+ * step >= 1 is the bias-correction exponent; norm_and_coef (may be NULL) is the output of sgl_op_grad_norm. */
+int sgl_op_adamw(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double beta1, double beta2,
+                 double eps, int step, const float* norm_and_coef, sgl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

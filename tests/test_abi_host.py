@@ -125,3 +125,15 @@ def test_from_pretrained_local_dir_and_open_clip_factory_errors(pkg, tmp_path):
     assert m2.config.num_hidden_layers == 3
     with pytest.raises(OSError):
         pkg.SiglipVisionModelHIP.from_pretrained("google/not-a-model")
+
+
+def test_adamw_plan_host_helper(hiplib):
+    """sgl_adamw_plan is host-only: (tensor, chunk) pairs of 4096 elements, in table order."""
+    lib = hiplib
+    numel = (C.c_uint64 * 4)(1, 4096, 4097, 0)
+    nb = lib.sgl_adamw_plan(numel, 4, None, 0)
+    assert nb == 4
+    bm = (C.c_int32 * (2 * nb))()
+    assert lib.sgl_adamw_plan(numel, 4, bm, nb) == nb
+    assert list(bm) == [0, 0, 1, 0, 2, 0, 2, 1]
+    assert lib.sgl_adamw_plan(None, 1, None, 0) < 0
