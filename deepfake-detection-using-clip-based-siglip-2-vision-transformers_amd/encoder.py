@@ -261,6 +261,19 @@ class _EncoderFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------
 # surface H
 # ---------------------------------------------------------------------------------------------------------
+def _hf_state_dict_hook(module, state_dict, prefix, local_metadata):
+    """state_dict(): parameters are registered without the ``vision_model.`` level; add it on the way out."""
+    for k in [k for k in state_dict if k.startswith(prefix) and not k.startswith(prefix + "vision_model.")]:
+        state_dict[prefix + "vision_model." + k[len(prefix):]] = state_dict.pop(k)
+
+
+def _hf_load_pre_hook(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    """load_state_dict(): strip the ``vision_model.`` level (also when this module is nested in a parent)."""
+    pv = prefix + "vision_model."
+    for k in [k for k in state_dict if k.startswith(pv)]:
+        state_dict[prefix + k[len(pv):]] = state_dict.pop(k)
+
+
 class SiglipVisionModelHIP(nn.Module):
     """Drop-in for ``transformers.SiglipVisionModel`` on the reference's path (see module docstring)."""
 
@@ -287,6 +300,9 @@ class SiglipVisionModelHIP(nn.Module):
         self._grad_reducer = None
         self._gradient_checkpointing = False
         self._flat_names = self._build_names()
+        # checkpoints keep transformers' key names (``vision_model.encoder.layers.N…``, Siglip2sidafrozen.py:1639)
+        self._register_state_dict_hook(_hf_state_dict_hook)
+        self._register_load_state_dict_pre_hook(_hf_load_pre_hook)
 
     # ---- HF surface ------------------------------------------------------------------------------------
     @property
@@ -323,11 +339,12 @@ class SiglipVisionModelHIP(nn.Module):
         self._gradient_checkpointing = True
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        sd = {}
-        for k, v in state_dict.items():
-            k2 = k[len("vision_model."):] if k.startswith("vision_model.") else k
-            sd[k2] = v
-        return super().load_state_dict(sd, strict=strict, **kw)
+        """Accepts HF names with or without the ``vision_model.`` prefix, or an open_clip/timm vision tower
+        (``…visual.trunk.blocks.N.attn.qkv.weight``, converted by ``weights_io.timm_to_hf``)."""
+        from . import weights_io
+        if weights_io.detect_format(state_dict.keys()) == "timm":
+            state_dict = weights_io.encoder_state_from_checkpoint(state_dict, self.config)
+        return super().load_state_dict(dict(state_dict), strict=strict, **kw)
 
     def forward(self, pixel_values, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
                 hidden_state_ids=None, **_):
@@ -468,6 +485,31 @@ class OpenClipStyleEncoder(nn.Module):
         self.visual = SiglipVisionModelHIP(config, compute_dtype)
         self.embed_dim = self.visual.config.hidden_size
         self.image_size = self.visual.config.image_size
+        # checkpoints keep open_clip's key names (``visual.trunk.blocks.N.attn.qkv.weight``): the reference saves and
+        # reloads ``backbone.visual.trunk.*`` (cifake_binary_classifier.py:2089, train_fusion_head_only.py:110-122)
+        self._register_state_dict_hook(self._timm_state_dict_hook)
+        self._register_load_state_dict_pre_hook(self._timm_load_pre_hook, with_module=True)
+
+    @staticmethod
+    def _timm_state_dict_hook(module, state_dict, prefix, local_metadata):
+        from . import weights_io
+        pv = prefix + "visual.vision_model."
+        hf = {k[len(pv):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(pv)]}
+        for k, v in weights_io.hf_to_timm(hf, module.visual.config, "trunk.").items():
+            state_dict[prefix + "visual." + k] = v
+
+    @staticmethod
+    def _timm_load_pre_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                            error_msgs):
+        from . import weights_io
+        pt = prefix + "visual.trunk."
+        if any(k.startswith(pt) for k in state_dict):
+            timm = {k[len(prefix + "visual."):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(pt)]}
+            for k, v in weights_io.timm_to_hf(timm, module.visual.config, "trunk.").items():
+                state_dict[prefix + "visual." + k] = v
+        for k in [k for k in state_dict if k.startswith(prefix + "text.") or k == prefix + "logit_scale"
+                  or k == prefix + "logit_bias"]:
+            state_dict.pop(k)  # the text tower is never used on this path (train_fusion_head_only.py:115)
 
     def encode_image(self, x, normalize: bool = False):
         out = self.visual(pixel_values=x, interpolate_pos_encoding=False)

@@ -473,7 +473,32 @@ def mtl_loss(cls_logit, seg_logits, y_class, masks, has_mask, lam_seg: float = 1
 # ---------------------------------------------------------------------------------------------------------
 # composed task models (reference L3 modules: encoder surface O + head)
 # ---------------------------------------------------------------------------------------------------------
-class FastBinaryClassifierHIP(nn.Module):
+class _FlatHeadKeys(nn.Module):
+    """The reference's task models own their head layers directly (``se.0.weight``, ``classifier.5.bias`` …), ours
+    keep them in ``self.head``; checkpoints use the reference's names, so the ``head.`` level is dropped on
+    ``state_dict()`` and re-inserted on ``load_state_dict()`` (cifake_binary_classifier.py:2089,
+    train_fusion_head_only.py:110-122)."""
+
+    def __init__(self):
+        super().__init__()
+        self._register_state_dict_hook(self._flat_out)
+        self._register_load_state_dict_pre_hook(self._flat_in, with_module=True)
+
+    @staticmethod
+    def _flat_out(module, state_dict, prefix, local_metadata):
+        ph = prefix + "head."
+        for k in [k for k in state_dict if k.startswith(ph)]:
+            state_dict[prefix + k[len(ph):]] = state_dict.pop(k)
+
+    @staticmethod
+    def _flat_in(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        own = {n.split(".")[0] for n, _ in module.head.named_parameters()} | \
+              {n.split(".")[0] for n, _ in module.head.named_buffers()}
+        for k in [k for k in state_dict if k.startswith(prefix) and k[len(prefix):].split(".")[0] in own]:
+            state_dict[prefix + "head." + k[len(prefix):]] = state_dict.pop(k)
+
+
+class FastBinaryClassifierHIP(_FlatHeadKeys):
     """`FastBinaryClassifier.forward` (cifake_binary_classifier.py:714-749) on the HIP encoder: bilinear resize to
     the model resolution if needed → `backbone.encode_image` → head."""
 
@@ -491,7 +516,7 @@ class FastBinaryClassifierHIP(nn.Module):
         return self.head(self.backbone.encode_image(x), return_features)
 
 
-class BinaryVideoClassifierHIP(nn.Module):
+class BinaryVideoClassifierHIP(_FlatHeadKeys):
     """`BinaryVideoClassifier.forward` (hidf_video_classifier.py:299-320): (B,T,C,H,W) → per-frame encoder →
     L2-norm → temporal mean → MLP → (B,) logits."""
 
@@ -507,7 +532,7 @@ class BinaryVideoClassifierHIP(nn.Module):
         return self.head(self.vision_encoder.encode_image(x.view(b * t, c, h, w)), batch_size=b)
 
 
-class SEBinaryClassifierHIP(nn.Module):
+class SEBinaryClassifierHIP(_FlatHeadKeys):
     """`BinaryClassifier.forward` of the fusion script (train_fusion_head_only.py:101-109): frozen encoder under
     no_grad, nearest-neighbour resize to the model size, SE gate + MLP."""
 

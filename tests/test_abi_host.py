@@ -66,9 +66,9 @@ def test_state_dict_matches_hf_names_and_freezing_surface(pkg):
     m = pkg.SiglipVisionModelHIP(cfg, compute_dtype="fp32")
     ref_shapes = pkg.weights.param_shapes(cfg)
     sd = m.state_dict()
-    assert list(sd.keys()) == list(ref_shapes.keys())       # HF SiglipVisionModel key order and names
+    assert list(sd.keys()) == ["vision_model." + k for k in ref_shapes]   # transformers' SiglipVisionModel keys, in order
     for k, v in sd.items():
-        assert tuple(v.shape) == tuple(ref_shapes[k]), k
+        assert tuple(v.shape) == tuple(ref_shapes[k[len("vision_model."):]]), k
     assert sum(p.numel() for p in m.parameters()) == cfg.num_params()
     seeded = pkg.weights.seeded_state_dict(cfg, 1)
     m.load_state_dict(seeded)
@@ -120,7 +120,7 @@ def test_from_pretrained_local_dir_and_open_clip_factory_errors(pkg, tmp_path):
     (d / "config.json").write_text(json.dumps({"vision_config": cfg.to_dict()}))
     save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
     m = pkg.SiglipVisionModelHIP.from_pretrained(str(d), compute_dtype="fp32")
-    assert torch.equal(m.state_dict()["head.probe"], sd["head.probe"])
+    assert torch.equal(m.state_dict()["vision_model.head.probe"], sd["head.probe"])
     m2 = pkg.SiglipVisionModelHIP.from_pretrained("tiny")
     assert m2.config.num_hidden_layers == 3
     with pytest.raises(OSError):
