@@ -249,6 +249,280 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Anti-phase ("ping-pong") main loops, generation 6 (default).  The two wave groups of the workgroup (G0 = waves
+// 0-3, G1 = waves 4-7; every SIMD holds one wave of each) alternate: time is cut into slots separated by workgroup
+// barriers, and in every slot one group issues the LDS reads of its next half K-step (plus its share of the
+// global->LDS DMA stream) while the other group issues 32 MFMAs, so each SIMD's matrix pipe always has exactly one
+// wave feeding it and nobody's LDS latency is exposed.  G1 simply starts one barrier late.  Measured against the
+// generation-2 loop (one barrier per K-step, rolling fragment prefetch) in the same process: +8..14 % on the
+// encoder's NT shapes, 1.29 -> 1.45 PFLOP/s at 8192^3.  Variants tried and dropped: 8 slots of 16 MFMAs (+4 %; the
+// barrier hand-off costs about as much per slot regardless of slot length), 2 slots of 64 MFMAs (needs all DMA
+// issued one slot before use: the prefetch distance is too short, -12 %).
+//
+// LDS-DMA is issued through inline asm: with the builtin the compiler cannot prove that a ds_read_b64_tr_b16 does not
+// alias the in-flight DMA and drains vmcnt(0) in front of every transposed read.  The kernels own the vmcnt
+// accounting instead: every read slot ends with s_waitcnt vmcnt(8) (four younger 2-instruction units may stay in
+// flight), and the schedule guarantees that (a) a unit is issued at least 4 slots = one K-step
+// before the wait that publishes it, (b) both groups have passed that wait and a barrier before anyone reads it,
+// (c) a unit is issued only after both groups finished (lgkmcnt(0) + barrier) reading the unit it overwrites.
+__device__ __forceinline__ void pp_dma16(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(desc) : "memory");
+}
+__device__ __forceinline__ u32x4 pp_desc(const void* base, uint32_t bytes) {
+  const uint64_t q = (uint64_t)base;
+  u32x4 d = {(uint32_t)q, (uint32_t)(q >> 32) & 0xffffu, bytes, 0x00020000u};
+  return d;
+}
+#define SGL_PP_END_READ8()                                              \
+  do {                                                                  \
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    __builtin_amdgcn_s_barrier();                                       \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+  } while (0)
+#define SGL_PP_END_MFMA()                 \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+// NT, four slots per K-step.  The global->LDS stream moves 16-KiB units in the fixed round-robin order
+//     Aq02(t) = A rows {0-63,128-191},  BX(t) = first 32 columns of every wave column,  BY(t) = the other 32,
+//     Aq13(t) = A rows {64-127,192-255},  Aq02(t+1), ...          (two wave-instructions per wave per unit)
+// Per wave and K-step t:
+//     R1(t): 16 fragment reads (A0 = rows 0-63 of the wave's 128, B0, B1 = all 64 columns) + DMA unit Aq13(t+1)
+//     M1(t): A0 x (B0,B1)   32 MFMAs
+//     R2(t):  8 fragment reads (A1 = rows 64-127)                 + DMA units Aq02(t+2), BX(t+2), BY(t+2)
+//     M2(t): A1 x (B0,B1)   32 MFMAs
+// G0 runs R1 in slot 4t, G1 in slot 4t+1.
+template <int EPI, typename TOut>
+__global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict__ A, int lda,
+                                                          const bf16* __restrict__ B, int ldb, int M, int N, int K,
+                                                          int tiles_m, int tiles_n, EpiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = tiles_m * tiles_n;
+  const int unit = unit_of_block(blockIdx.x, (ntiles + 7) >> 3);
+  if (unit >= ntiles) return;  // whole block exits together
+  int tile_m, tile_n;
+  tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2), grp = w >> 2;
+  const int m0 = tile_m * T_BM, n0 = tile_n * T_BN;
+  const int rows_a = (M - m0 < T_BM) ? M - m0 : T_BM;
+  const int rows_b = (N - n0 < T_BN) ? N - n0 : T_BN;
+  const u32x4 da = pp_desc(A + (size_t)m0 * lda, (uint32_t)(((size_t)(rows_a - 1) * lda + K) * 2));
+  const u32x4 db = pp_desc(B + (size_t)n0 * ldb, (uint32_t)(((size_t)(rows_b - 1) * ldb + K) * 2));
+  const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
+
+  const int drow = lane >> 3, dchunk = (lane & 7) ^ drow;
+  uint32_t voff[4][2], ldst[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ul = 16 * w + 8 * q;  // unit-local first row of the instruction (multiple of 8)
+      int r0;
+      if (u == 0) r0 = (ul < 64) ? ul : ul + 64;
+      else if (u == 3) r0 = (ul < 64) ? ul + 64 : ul + 128;
+      else r0 = (ul >> 5) * 64 + (ul & 31) + (u == 2 ? 32 : 0);
+      const int row = r0 + drow;
+      const bool isA = (u == 0 || u == 3);
+      const int lim = isA ? rows_a : rows_b;
+      const int ld = isA ? lda : ldb;
+      voff[u][q] = (row < lim) ? (uint32_t)(row * ld + dchunk * 8) * 2u : SGL_OOB;
+      ldst[u][q] = lds0 + (isA ? 0 : T_OP) + (uint32_t)r0 * 128u;
+    }
+  const int nk = (K + T_BK - 1) / T_BK;
+  auto issue = [&](int u, int kt) {  // unit u of K-step kt (K-steps past the end: all lanes out of range -> zeros)
+    const int k0 = kt * T_BK;
+    const bool kok = (kt < nk) && (k0 + dchunk * 8 < K);
+    const uint32_t sb = (uint32_t)((kt & 1) * T_STAGE);
+    const u32x4 d = (u == 0 || u == 3) ? da : db;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      pp_dma16(d, ldst[u][q] + sb, (kok && voff[u][q] != SGL_OOB) ? voff[u][q] + (uint32_t)k0 * 2u : SGL_OOB);
+  };
+
+  const int frow = lane & 15, fg = lane >> 4, fsw = frow & 7;
+  const uint32_t fa_base = (uint32_t)((wr * 128 + frow) * 128);
+  const uint32_t fb_base = (uint32_t)(T_OP + (wc * 64 + frow) * 128);
+  const uint32_t c0 = (uint32_t)(((0 + fg) ^ fsw) << 4), c1 = (uint32_t)(((4 + fg) ^ fsw) << 4);
+  const bool active = (n0 + wc * 64 < N) && (m0 + wr * 128 < M);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  issue(0, 1); issue(1, 1); issue(2, 1);
+  SGL_PP_END_READ8();                // Aq02(0), BX(0), BY(0) of every wave have landed
+  if (grp == 1) SGL_PP_END_MFMA();   // G1 runs one slot behind G0 from here on
+
+  bf16x8 fa[8], fb[8];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + (kt & 1) * T_STAGE;
+    const char* pa = base + fa_base;
+    const char* pb = base + fb_base;
+    // ---- R1: A0 (row tiles 0-3), B (column tiles 0-3), both k-halves
+    if (active) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fb[f] = *reinterpret_cast<const bf16x8*>(pb + (f & 3) * 2048 + ((f >> 2) ? c1 : c0));
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fa[f] = *reinterpret_cast<const bf16x8*>(pa + (f & 3) * 2048 + ((f >> 2) ? c1 : c0));
+    }
+    issue(3, kt + 1);
+    SGL_PP_END_READ8();
+    if (active) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[4 * h + i], fb[4 * h + j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    SGL_PP_END_MFMA();
+    // ---- R2: A1 (row tiles 4-7)
+    if (active) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fa[f] = *reinterpret_cast<const bf16x8*>(pa + (4 + (f & 3)) * 2048 + ((f >> 2) ? c1 : c0));
+    }
+    issue(0, kt + 2); issue(1, kt + 2); issue(2, kt + 2);
+    SGL_PP_END_READ8();
+    if (active) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[4 * h + i], fb[4 * h + j], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    SGL_PP_END_MFMA();
+  }
+  if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
+  store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TN (dW), four slots per K-step of 64 tokens, split by K-HALF: the token index is the MFMA k index, so the first 32
+// image rows of both operands feed the first 32 MFMAs (every accumulator once) and the last 32 rows the other 32.
+//     R1(t): k-half 0 fragments (8 A + 4 B, two transposed reads each) + DMA units U2(t+1), U3(t+1)
+//     M1(t): 32 MFMAs      R2(t): k-half 1 fragments + DMA units U0(t+2), U1(t+2)      M2(t): 32 MFMAs
+// units: U0 = A image rows 0-31, U1 = B rows 0-31, U2 = A rows 32-63, U3 = B rows 32-63 (16 KiB each).
+__global__ __launch_bounds__(512, 2) void gemm_tn6_kernel(const bf16* __restrict__ A, int lda,
+                                                          const bf16* __restrict__ B, int ldb, int Mred, int N1, int N2,
+                                                          int m_per_split, int nsplits, int tiles_1, int tiles_2,
+                                                          EpiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = tiles_1 * tiles_2;
+  const int nunits = ntiles * nsplits;
+  const int unit = unit_of_block(blockIdx.x, (nunits + 7) >> 3);
+  if (unit >= nunits) return;
+  const int split = unit / ntiles, trem = unit - split * ntiles;
+  const int tile1 = trem / tiles_2, tile2 = trem - tile1 * tiles_2;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2), grp = w >> 2;
+  const int n1_0 = tile1 * T_BM, n2_0 = tile2 * T_BN;
+  const int m_begin = split * m_per_split;
+  const int m_end = (m_begin + m_per_split < Mred) ? m_begin + m_per_split : Mred;
+  const int rows = m_end - m_begin;
+  const u32x4 da = pp_desc(A + (size_t)m_begin * lda, (uint32_t)((size_t)rows * lda * 2));
+  const u32x4 db = pp_desc(B + (size_t)m_begin * ldb, (uint32_t)((size_t)rows * ldb * 2));
+  const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
+
+  // DMA plan: unit u = 2*khalf + operand; wave w moves image rows 32*khalf + 4w + {0..3}, 2 rows (1 KiB) per
+  // instruction; slot s of row m holds source chunk s ^ (2*(m&3) + 8*((m>>3)&1)) (same image as tn2)
+  const int dr2 = lane >> 5, dslot = lane & 31;
+  uint32_t voff[4][2], ldst[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r0 = 32 * (u >> 1) + 4 * w + 2 * q;
+      const int row = r0 + dr2;
+      const int chunk = dslot ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
+      const bool isA = (u & 1) == 0;
+      const int col = (isA ? n1_0 : n2_0) + chunk * 8;
+      const int lim = isA ? N1 : N2;
+      const int ld = isA ? lda : ldb;
+      voff[u][q] = (col < lim) ? (uint32_t)(row * ld + col) * 2u : SGL_OOB;
+      ldst[u][q] = lds0 + (isA ? 0 : T_OP) + (uint32_t)r0 * 512u;
+    }
+  auto issue = [&](int u, int kt) {  // rows past the split's range are out of range for the descriptor -> zeros
+    const uint32_t r0 = (uint32_t)kt * T_BK;
+    const uint32_t sb = (uint32_t)((kt & 1) * T_STAGE);
+    const bool isA = (u & 1) == 0;
+    const u32x4 d = isA ? da : db;
+    const uint32_t adv = r0 * (uint32_t)(isA ? lda : ldb) * 2u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) pp_dma16(d, ldst[u][q] + sb, voff[u][q] == SGL_OOB ? SGL_OOB : voff[u][q] + adv);
+  };
+
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  const uint32_t swz = (uint32_t)(32 * fq + 128 * (fg & 1));
+  const uint32_t frow = (uint32_t)((8 * fg + fq) * 512);
+  const uint32_t fa_col = ((uint32_t)(wr * 256 + 8 * fp)) ^ swz;
+  const uint32_t fb_col = ((uint32_t)(wc * 128 + 8 * fp)) ^ swz;
+  const bool active = (n2_0 + wc * 64 < N2) && (n1_0 + wr * 128 < N1);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (rows + T_BK - 1) / T_BK;
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+  issue(0, 1); issue(1, 1);
+  SGL_PP_END_READ8();                // U0(0), U1(0) of every wave have landed
+  if (grp == 1) SGL_PP_END_MFMA();   // G1 runs one slot behind G0 from here on
+
+#define SGL_TR6(ptr) __builtin_shufflevector(lds_tr16v2(ptr), lds_tr16v2((ptr) + 4 * 512), 0, 1, 2, 3, 4, 5, 6, 7)
+  bf16x8 fa[8], fb[4];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + (kt & 1) * T_STAGE + frow;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = SGL_TR6(base + T_OP + h * 32 * 512 + (fb_col ^ (uint32_t)(j * 32)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = SGL_TR6(base + h * 32 * 512 + (fa_col ^ (uint32_t)(i * 32)));
+      }
+      if (h == 0) { issue(2, kt + 1); issue(3, kt + 1); }
+      else { issue(0, kt + 2); issue(1, kt + 2); }
+      SGL_PP_END_READ8();
+      if (active) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      SGL_PP_END_MFMA();
+    }
+  }
+#undef SGL_TR6
+  if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
+  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict__ A, int lda,
                                                           const bf16* __restrict__ B, int ldb, int Mred, int N1, int N2,
                                                           int m_per_split, int nsplits, int tiles_1, int tiles_2,
@@ -352,6 +626,19 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
   }
   const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + T_BN - 1) / T_BN;
   const int grid = ((tiles_m * tiles_n + 7) / 8) * 8;
+  static const int gen = getenv("SGL_GEMM_GEN") ? atoi(getenv("SGL_GEMM_GEN")) : 6;
+  if (gen != 2) {
+    static bool attr6 = false;
+    if (!attr6) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt6_kernel<EPI, TOut>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+      if (e != hipSuccess) return e;
+      attr6 = true;
+    }
+    hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
+                       tiles_m, tiles_n, p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
                      tiles_n, p);
   return hipGetLastError();
@@ -386,6 +673,20 @@ hipError_t gemm_tn2_bf16(const void* A_, int lda, const void* B_, int ldb, int M
   }
   const int tiles_1 = (N1 + T_BM - 1) / T_BM, tiles_2 = (N2 + T_BN - 1) / T_BN;
   const int grid = ((tiles_1 * tiles_2 * splits + 7) / 8) * 8;
+  static const int gen = getenv("SGL_GEMM_GEN") ? atoi(getenv("SGL_GEMM_GEN")) : 6;
+  static const int tngen = getenv("SGL_TN_GEN") ? atoi(getenv("SGL_TN_GEN")) : gen;
+  if (tngen != 2) {
+    static bool attr6 = false;
+    if (!attr6) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn6_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+      if (e != hipSuccess) return e;
+      attr6 = true;
+    }
+    hipLaunchKernelGGL(gemm_tn6_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
+                       Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
                      Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
   return hipGetLastError();
