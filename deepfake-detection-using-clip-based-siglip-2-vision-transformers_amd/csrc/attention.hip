@@ -65,7 +65,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // forward
 // ======================================================================================================
 template <int DP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int H, int N, int dh, float c,
                                                           float scale) {

@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiglip_hip.so")
+LIB_PATH = os.environ.get("SGL_LIB_PATH") or os.path.join(_HERE, "libsiglip_hip.so")  # override: developer A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "siglip_hip.h")
 
 SGL_DTYPE_F32, SGL_DTYPE_BF16 = 0, 1
