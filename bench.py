@@ -99,7 +99,7 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if batch == 64 and os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch, measured offline
         traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "sgl::gemm_nt2_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
+    return {"bound": "mfma", "kernel": "sgl::gemm_nt6_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
             "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
