@@ -1,10 +1,12 @@
-// Second-generation bf16 MFMA GEMMs for gfx950: 256x256 output tile, K-step 64, 512 threads = 8 waves, operands
-// streamed global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no VGPR staging),
-// two LDS stages (2 x 64 KiB), one barrier per K-step: the DMA for step t+1 is issued right after the barrier
-// that retires step t's DMA and runs under step t's 64 MFMAs per wave.
+// bf16 MFMA GEMMs for gfx950 on a 256x256 output tile, K-step 64, 512 threads = 8 waves, operands streamed
+// global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no VGPR staging), two LDS stages
+// (2 x 64 KiB).  Two main-loop generations share the images, tile order and epilogues:
+//   nt6 / tn6 (default): anti-phase wave groups, four barrier-separated slots per K-step (see the comment above them)
+//   nt2 / tn2 (SGL_GEMM_GEN=2): one barrier per K-step, the DMA for step t+1 is issued right after the barrier that
+//                               retires step t's DMA and runs under step t's 64 MFMAs per wave
 //
-//   nt2 : C[M,N]   = A[M,K] · B[N,K]ᵀ           (forward projections, dX with transposed weight shadows)
-//   tn2 : C[N1,N2] (+)= Σ_m A[m,N1] · B[m,N2]    (dW; token index is the MFMA k index via ds_read_b64_tr_b16)
+//   nt : C[M,N]   = A[M,K] · B[N,K]ᵀ           (forward projections, dX with transposed weight shadows)
+//   tn : C[N1,N2] (+)= Σ_m A[m,N1] · B[m,N2]    (dW; token index is the MFMA k index via ds_read_b64_tr_b16)
 //
 // Arithmetic intensity of the tile: 2*256*256*64 / (2*256*64*2 B) = 128 FLOP per LDS-staged byte (the 128x128
 // tile of gemm_bf16.hip has 64 and is L2->LDS bandwidth bound near 0.6-0.7 PFLOP/s on this chip).
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict
 // LDS-DMA is issued through inline asm: with the builtin the compiler cannot prove that a ds_read_b64_tr_b16 does not
 // alias the in-flight DMA and drains vmcnt(0) in front of every transposed read.  The kernels own the vmcnt
 // accounting instead: every read slot ends with s_waitcnt vmcnt(8) (four younger 2-instruction units may stay in
-// flight), and the schedule guarantees (DESIGN.md section 5) that (a) a unit is issued at least 4 slots = one K-step
+// flight), and the schedule guarantees (DESIGN.md section 4a) that (a) a unit is issued at least 4 slots = one K-step
 // before the wait that publishes it, (b) both groups have passed that wait and a barrier before anyone reads it,
 // (c) a unit is issued only after both groups finished (lgkmcnt(0) + barrier) reading the unit it overwrites.
 __device__ __forceinline__ void pp_dma16(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
