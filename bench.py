@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="so400m-patch14-384")
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (SURVEY.md 8d sweep: 16..128)")
     ap.add_argument("--res", type=int, default=0, help="image side (default: the config's native size)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,15 +95,17 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
         tot_f += fl
         del A, Bw, out, out2, res_t
     achieved = tot_f / tot_t / 1e12
-    traffic = None
+    traffic, alg_bytes = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if batch == 64 and os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch, measured offline
-        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+    if os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch at this batch, measured offline
+        ent = json.load(open(tpath)).get("by_batch", {}).get(str(batch))
+        if ent and res == cfg.image_size and cfg.hidden_size == 1152:
+            traffic, alg_bytes = ent["traffic_bytes_per_launch"], ent["algorithmic_bytes_per_launch"]
     return {"bound": "mfma", "kernel": "sgl::gemm_nt6_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
             "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                            "profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: 523.6 MB",
+                            f"profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: {alg_bytes}",
             "per_shape": per}
 
 
