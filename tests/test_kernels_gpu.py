@@ -90,7 +90,8 @@ def call_gemm_nt(lib, dtype, A, B, M, N, K, epi, out, ldo, out2=None, ldo2=0, bi
 GEMM_SHAPES = [(128, 128, 64), (1, 8, 8), (200, 136, 72), (729, 1152, 1152), (1458, 3456, 1152), (300, 1152, 4352),
                (64, 4352, 1152), (257, 144, 640),
                # large enough for the 256x256-tile LDS-DMA generation (M >= 2048, N >= 256), with M/N/K tails
-               (4096, 1152, 1152), (2300, 4352, 1152), (2125, 1152, 4352), (2916, 3456, 1152), (2049, 264, 72)]
+               (4096, 1152, 1152), (2300, 4352, 1152), (2125, 1152, 4352), (2916, 3456, 1152), (2049, 264, 72),
+               (2100, 304, 40), (2560, 512, 64), (2051, 1160, 200)]   # one K-step / exactly one / odd tails
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -171,7 +172,8 @@ def test_gemm_nt_qkv_scatter(lib, dtype, batch, tokens, heads, hd):
 @pytest.mark.parametrize("Mred,N1,N2,splits", [(64, 128, 128, 1), (729, 144, 144, 1), (1458, 1152, 1152, 4),
                                                  (2187, 538, 144, 3), (300, 256, 588, 1), (5000, 4304, 1152, 2),
                                                  (130, 8, 16, 1), (4100, 3456, 1152, 1), (2048, 1152, 1152, 1),
-                                                 (2916, 1152, 4304, 1), (2500, 538, 640, 1), (9000, 1152, 588, 1)])
+                                                 (2916, 1152, 4304, 1), (2500, 538, 640, 1), (9000, 1152, 588, 1),
+                                                 (2048, 512, 512, 16), (2090, 520, 1152, 8), (2048, 1152, 512, 1)])
 @pytest.mark.parametrize("dtype", [BF16, F32])
 def test_gemm_tn(lib, Mred, N1, N2, splits, dtype):
     torch.manual_seed(Mred + N1)
