@@ -7,4 +7,4 @@ from .config import SiglipVisionConfig, get_config, NAMED_CONFIGS  # noqa: F401
 from .encoder import (SiglipVisionModelHIP, OpenClipStyleEncoder, create_model_and_transforms,  # noqa: F401
                       VisionModelOutput)
 from .ddp import GradBucketReducer  # noqa: F401
-from .optim import FusedAdamW, global_grad_norm  # noqa: F401
+from .optim import FusedAdamW, global_grad_norm, ExponentialMovingAverage  # noqa: F401

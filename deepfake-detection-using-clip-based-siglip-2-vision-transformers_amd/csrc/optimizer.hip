@@ -147,9 +147,48 @@ __global__ __launch_bounds__(256) void adamw_kernel(const sgl_adamw_tensor* __re
   }
 }
 
+// shadow <- shadow*decay + p*(1-decay) for every table entry (p = .p, shadow = .m); the reference's
+// ExponentialMovingAverage.update (cifake_binary_classifier.py:222-225) as one launch.  12 B/parameter.
+__global__ __launch_bounds__(256) void ema_kernel(const sgl_adamw_tensor* __restrict__ T,
+                                                  const int32_t* __restrict__ map, float decay, float omd) {
+  const int ti = map[2 * blockIdx.x], ch = map[2 * blockIdx.x + 1];
+  const float* p = T[ti].p;
+  float* sh = T[ti].m;
+  const uint64_t n = T[ti].n;
+  const uint64_t base = (uint64_t)ch * OPT_CHUNK;
+  if (((((uintptr_t)p) | ((uintptr_t)sh)) & 15) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t i = base + (uint64_t)(k * 256 + threadIdx.x) * 4;
+      if (i + 3 < n) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + i);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(sh + i);
+        *reinterpret_cast<f32x4*>(sh + i) = y * decay + x * omd;
+      } else {
+        for (uint64_t j = i; j < n && j < i + 4; ++j) sh[j] = sh[j] * decay + p[j] * omd;
+      }
+    }
+  } else {
+    for (int k = 0; k < 16; ++k) {
+      const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+      if (i < n) sh[i] = sh[i] * decay + p[i] * omd;
+    }
+  }
+}
+
 }  // namespace sgl
 
 extern "C" {
+
+int sgl_op_ema(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double decay,
+               sgl_stream stream) {
+  if (!table || !blockmap) return SGL_ERR_NULL;
+  if (nblocks < 0 || nblocks > 0x7fffffff) return SGL_ERR_BAD_SHAPE;
+  if (nblocks == 0) return SGL_OK;
+  hipLaunchKernelGGL(sgl::ema_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, table, blockmap,
+                     (float)decay, (float)(1.0 - decay));
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
 
 int64_t sgl_adamw_plan(const uint64_t* numel, int ntensors, int32_t* blockmap, int64_t capacity_pairs) {
   if (!numel || ntensors < 0) return SGL_ERR_NULL;

@@ -116,6 +116,7 @@ def load():
     _sig(lib, "sgl_adamw_plan", i64, [C.POINTER(C.c_uint64), i, C.POINTER(C.c_int32), i64])
     _sig(lib, "sgl_op_grad_norm", i, [_fp, _fp, i64, f, _fp, _fp, _fp])
     _sig(lib, "sgl_op_adamw", i, [_fp, _fp, i64, C.c_double, C.c_double, C.c_double, i, _fp, _fp])
+    _sig(lib, "sgl_op_ema", i, [_fp, _fp, i64, C.c_double, _fp])
     _lib = lib
     return lib
 

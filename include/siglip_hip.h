@@ -201,6 +201,10 @@ int sgl_op_grad_norm(const sgl_adamw_tensor* table, const int32_t* blockmap, int
  * step >= 1 is the bias-correction exponent; norm_and_coef (may be NULL) is the output of sgl_op_grad_norm. */
 int sgl_op_adamw(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double beta1, double beta2,
                  double eps, int step, const float* norm_and_coef, sgl_stream stream);
+/* Weight EMA of the CiFake trainer (ExponentialMovingAverage.update, cifake_binary_classifier.py:222-225):
+ * shadow = shadow*decay + p*(1-decay) for every table entry, with p = entry.p (read only) and shadow = entry.m. */
+int sgl_op_ema(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double decay,
+               sgl_stream stream);
 
 #ifdef __cplusplus
 }

@@ -115,3 +115,31 @@ def test_global_grad_norm_and_errors():
     cpu.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         pkg.FusedAdamW([cpu]).step()
+
+
+def test_ema_matches_reference_formula_and_swaps_weights():
+    """ExponentialMovingAverage.update/apply_shadow/restore against the reference's per-tensor loop
+    (cifake_binary_classifier.py:211-236), restated on the CPU."""
+    pkg = entry.load_package()
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.LayerNorm(53), torch.nn.Linear(53, 4101)).cuda()
+    model[1].bias.requires_grad = False                      # frozen tensors are not tracked (reference: requires_grad)
+    ema = pkg.ExponentialMovingAverage(model, decay=0.99)
+    assert "1.bias" not in ema.shadow and len(ema.shadow) == 5
+    ref = {n: p.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    for step in range(3):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        ema.update()
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                ref[n] = ref[n] * 0.99 + p.detach().cpu() * (1 - 0.99)
+    for n in ref:
+        torch.testing.assert_close(ema.shadow[n].cpu(), ref[n], rtol=2e-6, atol=1e-7)
+    live = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ema.apply_shadow()
+    assert torch.equal(model[0].weight, ema.shadow["0.weight"]) and torch.equal(model[1].bias, live["1.bias"])
+    ema.restore()
+    for n, p in model.named_parameters():
+        assert torch.equal(p, live[n])
