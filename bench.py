@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (SURVEY.md 8d sweep: 16..128)")
     ap.add_argument("--res", type=int, default=0, help="image side (default: the config's native size)")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--freeze-below", type=int, default=0,
+                    help="secondary metric (SURVEY.md 8d): freeze embeddings and blocks < K as Siglip2sidafrozen.py:757-768")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--kernel-reps", type=int, default=20)
@@ -201,6 +203,12 @@ def main():
     model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=args.mode)
     model.load_state_dict(pkg.weights.seeded_state_dict(cfg, seed=0))
     model = model.to(dev)
+    if args.freeze_below > 0:
+        for p in model.vision_model.embeddings.parameters():
+            p.requires_grad = False
+        for i, layer in enumerate(model.vision_model.encoder.layers):
+            for p in layer.parameters():
+                p.requires_grad = i >= args.freeze_below
     if world > 1:
         pkg.ddp.broadcast_parameters(model, src=0)
         pkg.GradBucketReducer().attach(model)
@@ -238,10 +246,18 @@ def main():
     value = images / dt
     gh = res // cfg.patch_size
     train_flops = cfg.train_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
+    if args.freeze_below > 0:  # fwd + 2*[(L-k)*layer + head]
+        Nn, D, I, L = gh * gh, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        layer = 8 * Nn * D * D + 4 * Nn * Nn * D + 4 * Nn * D * I
+        head = 4 * Nn * D * D + 4 * D * D + 4 * Nn * D + 4 * D * I
+        fwd = cfg.fwd_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
+        train_flops = fwd + 2 * ((L - min(args.freeze_below, L)) * layer + head)
 
     line = {
-        "metric": ("images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16" if args.config == "so400m-patch14-384"
-                   else f"images/sec (train fwd+bwd) {args.config}@{res} {args.mode}"),
+        "metric": ("images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16"
+                   if args.config == "so400m-patch14-384" and args.freeze_below == 0
+                   else f"images/sec (train fwd+bwd) {args.config}@{res} {args.mode}"
+                        + (f" blocks<{args.freeze_below} frozen" if args.freeze_below else "")),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.mode, "data": "synthetic",
