@@ -37,6 +37,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def _collect(self):
         ents = []
         for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):  # e.g. after load_state_dict of a torch AdamW state
+                raise RuntimeError("FusedAdamW implements plain AdamW only (amsgrad / maximize are not supported)")
             for p in group["params"]:
                 if p.grad is None:
                     continue
