@@ -156,12 +156,12 @@ __device__ __forceinline__ int unit_of_block(int bid, int per) { return (bid & 7
 
 // NT tile order: bands of 8 row-tiles, column-major inside a band ("grouped" order): 32 consecutive tiles form an
 // 8 x 4 block of the tile grid, i.e. 8 A panels + 4 B panels feed 32 tiles out of one L2.
-__device__ __forceinline__ void tile_of_unit(int u, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
-  const int band = u / (8 * tiles_n);
-  const int rows = (tiles_m - band * 8 < 8) ? tiles_m - band * 8 : 8;
-  const int r = u - band * 8 * tiles_n;
+__device__ __forceinline__ void tile_of_unit(int u, int tiles_m, int tiles_n, int& tile_m, int& tile_n, int bh = 8) {
+  const int band = u / (bh * tiles_n);
+  const int rows = (tiles_m - band * bh < bh) ? tiles_m - band * bh : bh;
+  const int r = u - band * bh * tiles_n;
   tile_n = r / rows;
-  tile_m = band * 8 + (r - tile_n * rows);
+  tile_m = band * bh + (r - tile_n * rows);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -305,13 +305,13 @@ __device__ __forceinline__ u32x4 pp_desc(const void* base, uint32_t bytes) {
 template <int EPI, typename TOut>
 __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict__ A, int lda,
                                                           const bf16* __restrict__ B, int ldb, int M, int N, int K,
-                                                          int tiles_m, int tiles_n, EpiParams p) {
+                                                          int tiles_m, int tiles_n, int band_h, EpiParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntiles = tiles_m * tiles_n;
   const int unit = unit_of_block(blockIdx.x, (ntiles + 7) >> 3);
   if (unit >= ntiles) return;  // whole block exits together
   int tile_m, tile_n;
-  tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n);
+  tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n, band_h);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2), grp = w >> 2;
@@ -640,8 +640,12 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
       if (e != hipSuccess) return e;
       attr6 = true;
     }
+    // band height of the grouped tile order: 8 row-tiles for wide outputs, 4 when there are few column tiles (measured
+    // on one box: qkv N=3456 +3 %, fc2 N=1152 +1.5 % with 4; fc1 N=4352 best with 8).  SGL_BAND overrides.
+    static const int band_env = getenv("SGL_BAND") ? atoi(getenv("SGL_BAND")) : 0;
+    const int band_h = band_env > 0 ? band_env : (tiles_n >= 16 ? 8 : 4);
     hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
-                       tiles_m, tiles_n, p);
+                       tiles_m, tiles_n, band_h, p);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
