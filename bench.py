@@ -189,11 +189,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    # rehearsal hooks (tests/test_bench_multiproc_gpu.py): every rank on one device over gloo; the driver never sets them
+    backend = os.environ.get("SGL_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGL_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     pkg = entry.load_package()
     pkg.lib.load()
     cfg = pkg.get_config(args.config)
