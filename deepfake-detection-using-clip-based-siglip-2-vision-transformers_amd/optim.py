@@ -125,6 +125,9 @@ class FusedAdamW(torch.optim.Optimizer):
                                             float(eps), step0 + 1, norm_ptr, stream), "sgl_op_adamw")
         for _, st, _ in ents:
             st["step"] += 1
+        # the kernel wrote the parameters behind autograd's back: bump their version counters, which is what everything
+        # that caches on `p._version` keys on (the encoder's bf16 weight shadows, saved-tensor checks)
+        torch.autograd.graph.increment_version([p for p, _, _ in ents])
         return loss
 
 

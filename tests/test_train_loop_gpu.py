@@ -1,0 +1,70 @@
+"""End-to-end train-step wrapper: forward -> loss -> backward -> clip -> AdamW, three steps, on the
+HIP encoder with FusedAdamW, against the same loop on the CPU oracle with torch.optim.AdamW + clip_grad_norm_
+(Siglip2sidafrozen.py:1375-1398 without the GradScaler, which bf16 does not need).  Catches anything that goes stale
+between steps (the bf16/fp32 weight shadows must follow the optimizer's in-place updates)."""
+import pytest
+import torch
+
+import __graft_entry__ as entry
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_three_training_steps_track_the_cpu_reference(mode, tol):
+    pkg, oracle = entry.load_package(), entry.load_oracle()
+    cfg = pkg.get_config("hostile")
+    sd0 = pkg.weights.seeded_state_dict(cfg, seed=11)
+    x = pkg.weights.seeded_pixels(4, 42, 42, seed=5)
+    target = torch.linspace(-1, 1, cfg.hidden_size).expand(4, -1).contiguous()
+    lr, wd, clip = 2e-3, 0.05, 0.5
+
+    # CPU reference loop
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    ropt = torch.optim.AdamW(list(ref.values()), lr=lr, weight_decay=wd)
+    ref_losses = []
+    for _ in range(3):
+        out = oracle.vision_forward(x, ref, cfg, False, True)
+        loss = ((out["pooler_output"] - target) ** 2).mean() + 0.1 * out["last_hidden_state"].square().mean()
+        ropt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), clip)
+        ropt.step()
+        ref_losses.append(loss.item())
+
+    # HIP loop
+    model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
+    model.load_state_dict(sd0)
+    model = model.cuda()
+    opt = pkg.FusedAdamW(model.parameters(), lr=lr, weight_decay=wd, max_grad_norm=clip)
+    xd, td = x.cuda(), target.cuda()
+    losses = []
+    for _ in range(3):
+        out = model(pixel_values=xd, interpolate_pos_encoding=True)
+        loss = ((out.pooler_output - td) ** 2).mean() + 0.1 * out.last_hidden_state.square().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= tol * abs(b), (losses, ref_losses)
+    assert ref_losses[2] < ref_losses[0]                       # the loop actually trains
+    got = {k[len("vision_model."):]: v for k, v in model.state_dict().items()}
+    # Adam normalises every element's step to ~lr whatever the size of its gradient, so an element whose gradient is at
+    # rounding-noise level moves by +-lr with a sign that no two implementations agree on: compare each tensor's error
+    # with how far the tensor MOVED (Frobenius norms), not element by element.
+    worst, who = 0.0, None
+    for k, v in ref.items():
+        if k.endswith("k_proj.bias"):
+            # softmax is invariant to a per-query constant: d loss / d k_bias is exactly zero in exact arithmetic, so the
+            # whole tensor is such noise
+            continue
+        diff = got[k].cpu() - v.detach()
+        moved = v.detach() - sd0[k]
+        if k == "head.attention.in_proj_bias":   # its middle third is the pooling attention's key bias: same argument
+            diff[cfg.hidden_size:2 * cfg.hidden_size] = 0
+        r = diff.norm().item() / (moved.norm().item() + 1e-12)
+        if r > worst:
+            worst, who = r, k
+    assert worst <= (2e-2 if mode == "fp32" else 0.35), (worst, who)
