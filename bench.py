@@ -97,6 +97,19 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
         tot_f += fl
         del A, Bw, out, out2, res_t
     achieved = tot_f / tot_t / 1e12
+    sclk = None
+    try:  # shader clock the chip holds while this kernel runs back to back (power-capped well below the 2.4 GHz boost)
+        A = torch.randn(M, D, device=dev).bfloat16()
+        Bw = (torch.randn(Ip, D, device=dev) / D ** 0.5).bfloat16()
+        out = torch.empty(M, Ip, device=dev, dtype=torch.bfloat16)
+
+        def launch_fc1():
+            lib.sgl_op_gemm_nt(1, A.data_ptr(), D, Bw.data_ptr(), D, M, Ip, D, 0, out.data_ptr(), Ip, None, 0, None, None,
+                               0, None, 0, None, 1, 1, 1, 8, 8, 1, stream.cuda_stream)
+        sclk = sustained_sclk_mhz(launch_fc1)
+        del A, Bw, out
+    except Exception:
+        sclk = None
     traffic, alg_bytes = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch at this batch, measured offline
@@ -106,6 +119,8 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
     return {"bound": "mfma", "kernel": "sgl::gemm_nt6_kernel (bf16 MFMA NT GEMM, the 4 forward shapes of one block)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s",
             "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
+            "sustained_sclk_mhz": sclk,
+            "sclk_note": "rocm-smi shader clock sampled while the kernel runs back to back for ~2 s; peak assumes 2400 MHz",
             "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                             f"profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: {alg_bytes}",
             "per_shape": per}
@@ -133,6 +148,37 @@ def optimizer_step_roofline(pkg, model, x, reps=10):
     return {"kernel": "sgl::grad_sqnorm_kernel + sgl::adamw_kernel (clip_grad_norm_ + AdamW.step, fp32)",
             "params": n, "ms": round(t * 1e3, 3), "bound": "hbm", "achieved": round(32.0 * n / t / 1e9, 1),
             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(32.0 * n / t / PEAK_HBM, 4)}
+
+
+def sustained_sclk_mhz(launch, seconds=2.0):
+    """Median rocm-smi sclk (MHz) over a few samples taken while `launch` is re-issued continuously; None when rocm-smi
+    is unavailable.  Informational: explains the distance between `peak` (datasheet, 2.4 GHz) and what the pool sustains."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def probe():
+        while not stop[0]:
+            try:
+                r = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", r)
+                if m:
+                    samples.append(int(m.group(1)))
+            except Exception:
+                return
+            time.sleep(0.2)
+    th = threading.Thread(target=probe, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            launch()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join(timeout=15)
+    samples = sorted(samples[1:] if len(samples) > 2 else samples)   # the first sample may predate the load
+    return samples[len(samples) // 2] if samples else None
 
 
 def host_cores() -> int:
