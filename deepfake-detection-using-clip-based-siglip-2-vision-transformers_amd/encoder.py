@@ -504,8 +504,15 @@ class OpenClipStyleEncoder(nn.Module):
         from . import weights_io
         pt = prefix + "visual.trunk."
         if any(k.startswith(pt) for k in state_dict):
-            timm = {k[len(prefix + "visual."):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(pt)]}
-            for k, v in weights_io.timm_to_hf(timm, module.visual.config, "trunk.").items():
+            timm = {k[len(prefix + "visual."):]: state_dict[k] for k in state_dict if k.startswith(pt)}
+            try:
+                hf = weights_io.timm_to_hf(timm, module.visual.config, "trunk.")
+            except (KeyError, ValueError) as e:   # incomplete / mis-shaped tower: report it the way torch reports keys
+                error_msgs.append(f"open_clip vision tower under '{pt}' cannot be converted: {e!r}")
+                return
+            for k in list(timm):
+                state_dict.pop(prefix + "visual." + k)
+            for k, v in hf.items():
                 state_dict[prefix + "visual." + k] = v
         for k in [k for k in state_dict if k.startswith(prefix + "text.") or k == prefix + "logit_scale"
                   or k == prefix + "logit_bias"]:

@@ -73,6 +73,10 @@ def test_open_clip_surface_speaks_timm_names_and_loads_reference_checkpoints(pkg
     model2 = pkg.heads.SEBinaryClassifierHIP(pkg.OpenClipStyleEncoder(cfg, "fp32"))
     model2.load_state_dict(state)
     assert torch.equal(model2.backbone.visual.head.probe, hf["head.probe"])
+    # an incomplete tower is reported as a load error, not a KeyError from inside the hook
+    broken = {k: v for k, v in state.items() if not k.endswith("trunk.norm.bias")}
+    with pytest.raises(RuntimeError, match="cannot be converted"):
+        pkg.heads.SEBinaryClassifierHIP(pkg.OpenClipStyleEncoder(cfg, "fp32")).load_state_dict(broken)
     # bare encoder accepts the same file too
     enc = pkg.SiglipVisionModelHIP(cfg, "fp32")
     enc.load_state_dict(state)
