@@ -434,4 +434,32 @@ hipError_t pool_attn_bwd(const float* q, const void* K, const void* V, int dtype
   return hipGetLastError();
 }
 
+// ---- split-K slabs -> result, fixed order -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ ws, int splits, size_t stride,
+                                                            int N1, int N2, float* __restrict__ out, int ldo,
+                                                            int accumulate) {
+  const size_t total4 = ((size_t)N1 * N2) >> 2;  // N2 % 4 == 0 (checked by the host)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const size_t e = i << 2;
+    const int r = (int)(e / N2), c = (int)(e - (size_t)r * N2);
+    f32x4 a = *reinterpret_cast<const f32x4*>(ws + e);
+    for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * stride + e);
+    float* o = out + (size_t)r * ldo + c;
+    if (accumulate) a += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = a;
+  }
+}
+
+hipError_t reduce_splits(const float* ws, int splits, size_t stride, int N1, int N2, float* out, int ldo, int accumulate,
+                         hipStream_t s) {
+  if ((N2 & 3) || (ldo & 3) || (((uintptr_t)out) & 15) || (((uintptr_t)ws) & 15) || (stride & 3))
+    return hipErrorInvalidValue;
+  const size_t total4 = ((size_t)N1 * N2) >> 2;
+  if (total4 == 0) return hipSuccess;
+  const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, ws, splits, stride, N1, N2, out, ldo,
+                     accumulate);
+  return hipGetLastError();
+}
+
 }  // namespace sgl

@@ -51,6 +51,9 @@ struct sgl_ctx {
 
 namespace {
 
+// splits * N1 * N2 * 4 bytes with tiles*splits <= 256 workgroups of 256x256 outputs: never more than 64 MiB
+constexpr size_t kSplitWsBytes = (size_t)256 * 256 * 256 * 4;
+
 // Per-call activation / workspace layout (pure function of ctx, B, grid, train).
 struct Layout {
   int B, gh, gw, N, M;
@@ -62,7 +65,7 @@ struct Layout {
   size_t a_pstats, a_lastlp, a_kvh, a_qp, a_probs, a_ao, a_h0, a_hstats, a_hl, a_hu, a_ha;
   size_t act_total;
   // backward scratch (ws)
-  size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_lnpart, w_cspart, w_dlast, w_gsum, w_csum;
+  size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_splitws, w_lnpart, w_cspart, w_dlast, w_gsum, w_csum;
   size_t w_hg, w_hdu, w_hdh, w_hdao, w_hdqpart, w_hdqp, w_hdh0;
   size_t ws_bwd_total;
   size_t saved_total, ws_total, ws_act_off;
@@ -113,9 +116,10 @@ struct Layout {
       w_dh = w.take(Mz * D * es);
       w_dqkv = w.take(Mz * 3 * D * es);
       w_delta = w.take((size_t)B * c->H * N * 4);
+      w_splitws = w.take(kSplitWsBytes);  // private slabs of the split-K dW GEMMs (deterministic reduction)
       w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 3 * D * 4);
       w_gsum = w.take(D * 4);        // column sums of the current d hidden_states (bias grad of the GEMM below)
-      w_csum = w.take(widest * 4);   // fused column sums coming out of a GEMM epilogue
+      w_csum = w.take((size_t)((M + 127) / 128) * widest * 4);   // per-row-tile column sums out of a GEMM epilogue
       w_cspart = w.take((size_t)colsum_chunks(M) * widest * 4);
       w_dlast = w.take(Mz * D * 4);
       w_hg = w.take((size_t)B * D * es);
@@ -126,7 +130,7 @@ struct Layout {
       w_hdqp = w.take(D * 4);
       w_hdh0 = w.take((size_t)B * D * 4);
     } else {
-      w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_lnpart = w_cspart = w_dlast = w_gsum = w_csum = 0;
+      w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_splitws = w_lnpart = w_cspart = w_dlast = w_gsum = w_csum = 0;
       w_hg = w_hdu = w_hdh = w_hdao = w_hdqpart = w_hdqp = w_hdh0 = 0;
     }
     ws_bwd_total = w.off;
@@ -164,7 +168,8 @@ hipError_t gemm_nt(const sgl_ctx* c, const void* A, int lda, const void* B, int 
 
 // dW[N1,N2] (+)= A[:, :N1]^T · B[:, :N2]   (reduction over the Mred rows)
 hipError_t gemm_tn(const sgl_ctx* c, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2,
-                   float* out, int ldo, int accumulate, hipStream_t s) {
+                   float* out, int ldo, int accumulate, hipStream_t s, void* split_ws = nullptr,
+                   size_t split_ws_bytes = 0) {
   EpiParams p;
   p.out = out;
   p.ldo = ldo;
@@ -175,7 +180,7 @@ hipError_t gemm_tn(const sgl_ctx* c, const void* A, int lda, const void* B, int 
     const int max_splits = Mred / 512 > 0 ? Mred / 512 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits > 16) splits = 16;
-    return gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, s);
+    return gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, s, reinterpret_cast<float*>(split_ws), split_ws_bytes);
   }
   return gemm_f32_generic((const float*)A, 1, lda, (const float*)B, 1, ldb, N1, N2, Mred, EPI_F32, DT_F32, p, s);
 }
@@ -611,7 +616,8 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
       CK(gemm_nt(ctx, dkv, 2 * D, at(shadow, ctx->sh_hwkv_t), 2 * D, M, D, 2 * D, EPI_F32, DT_F32, p, s));
     }
     if (g->in_proj_w)
-      CK(gemm_tn(ctx, dkv, 2 * D, act + lay.a_lastlp, D, M, 2 * D, D, g->in_proj_w + (size_t)D * D, D, acc, s));
+      CK(gemm_tn(ctx, dkv, 2 * D, act + lay.a_lastlp, D, M, 2 * D, D, g->in_proj_w + (size_t)D * D, D, acc, s,
+                 at(ws, lay.w_splitws), kSplitWsBytes));
     if (g->in_proj_b) RET(bias_grad(ctx, lay, ws, dkv, 2 * D, M, 2 * D, 2 * D, g->in_proj_b + D, acc, s));
     dlast = dlast_buf;
   }
@@ -655,6 +661,7 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   void* du = at(ws, lay.w_du);
   void* dhb = at(ws, lay.w_dh);
   void* dqkv = at(ws, lay.w_dqkv);
+  void* sws = at(ws, lay.w_splitws);
 
   // ---- MLP: x_out = xmid + fc2(gelu(fc1(LN2 xmid)))          gbuf = lowp(d x_out)
   float* gsum = reinterpret_cast<float*>(at(ws, lay.w_gsum));   // column sums of dx, left by the producer of dx
@@ -666,13 +673,14 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     p.ldo = Ip;
     p.aux = lb + lay.r_u;
     p.ldaux = Ip;
-    if (fuse_cs) {
-      CK(hipMemsetAsync(csum, 0, (size_t)Ip * 4, s));
+    if (fuse_cs) {  // deterministic: one row of partial sums per 128-row tile, folded in order below
+      CK(hipMemsetAsync(csum, 0, (size_t)((M + 127) / 128) * Ip * 4, s));
       p.colsum = csum;
+      p.colsum_ld = Ip;
     }
     CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.w2_t), D, M, Ip, D, EPI_GELU_BWD, dt, p, s));
   }
-  if (lg.fc2_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_a, Ip, M, D, I, lg.fc2_w, I, acc, s));
+  if (lg.fc2_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_a, Ip, M, D, I, lg.fc2_w, I, acc, s, sws, kSplitWsBytes));
   if (lg.fc2_b) CK(batch_sum(gsum, 1, (size_t)D, lg.fc2_b, acc, s));
   {
     EpiParams p;
@@ -680,9 +688,9 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     p.ldo = D;
     CK(gemm_nt(ctx, du, Ip, at(shadow, sl.w1_t), Ip, M, D, Ip, EPI_STORE, dt, p, s));
   }
-  if (lg.fc1_w) CK(gemm_tn(ctx, du, Ip, lb + lay.r_h2, D, M, I, D, lg.fc1_w, D, acc, s));
+  if (lg.fc1_w) CK(gemm_tn(ctx, du, Ip, lb + lay.r_h2, D, M, I, D, lg.fc1_w, D, acc, s, sws, kSplitWsBytes));
   if (fuse_cs)
-    CK(batch_sum(csum, 1, (size_t)I, lg.fc1_b, acc, s));
+    CK(reduce_partials(csum, (M + 127) / 128, Ip, lg.fc1_b, I, acc, s));
   else
     RET(bias_grad(ctx, lay, ws, du, Ip, M, Ip, I, lg.fc1_b, acc, s));
   // LN2 backward: dx := dx + LN2'(dh2);  gbuf := lowp(dx);  colsum(dx) is the out_proj bias gradient
@@ -696,7 +704,7 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     p.ldo = D;
     CK(gemm_nt(ctx, gbuf, D, at(shadow, sl.wo_t), D, M, D, D, EPI_STORE, dt, p, s));
   }
-  if (lg.o_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_attn, D, M, D, D, lg.o_w, D, acc, s));
+  if (lg.o_w) CK(gemm_tn(ctx, gbuf, D, lb + lay.r_attn, D, M, D, D, lg.o_w, D, acc, s, sws, kSplitWsBytes));
   {
     const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
     const char* q = lb + lay.r_qkv;
@@ -709,11 +717,11 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
     // when the caller laid the three gradients out back to back (the Python host does), q/k/v are one GEMM
     const bool w_adj = gw[0] && gw[1] == gw[0] + (size_t)D * D && gw[2] == gw[1] + (size_t)D * D;
     const bool b_adj = gb[0] && gb[1] == gb[0] + D && gb[2] == gb[1] + D;
-    if (w_adj) CK(gemm_tn(ctx, dqkv, 3 * D, lb + lay.r_h1, D, M, 3 * D, D, gw[0], D, acc, s));
+    if (w_adj) CK(gemm_tn(ctx, dqkv, 3 * D, lb + lay.r_h1, D, M, 3 * D, D, gw[0], D, acc, s, sws, kSplitWsBytes));
     if (b_adj) RET(bias_grad(ctx, lay, ws, dqkv, 3 * D, M, 3 * D, 3 * D, gb[0], acc, s));
     for (int j = 0; j < 3; ++j) {
       const char* aj = reinterpret_cast<const char*>(dqkv) + (size_t)j * D * ctx->es;
-      if (!w_adj && gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s));
+      if (!w_adj && gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s, sws, kSplitWsBytes));
       if (!b_adj) RET(bias_grad(ctx, lay, ws, aj, 3 * D, M, D, D, gb[j], acc, s));
     }
   }
@@ -742,7 +750,9 @@ int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, i
   const char* act = reinterpret_cast<const char*>(saved);
   float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
   void* gbuf = at(ws, lay.w_g);  // low-precision copy of dx (written by the last LN1 backward / begin)
-  if (g->patch_w) CK(gemm_tn(ctx, gbuf, D, act + lay.a_im2col, ctx->Kp, M, D, ctx->K0, g->patch_w, ctx->K0, acc, s));
+  if (g->patch_w)
+    CK(gemm_tn(ctx, gbuf, D, act + lay.a_im2col, ctx->Kp, M, D, ctx->K0, g->patch_w, ctx->K0, acc, s, at(ws, lay.w_splitws),
+               kSplitWsBytes));
   if (g->patch_b) CK(batch_sum(reinterpret_cast<const float*>(at(ws, lay.w_gsum)), 1, (size_t)D, g->patch_b, acc, s));
   if (g->pos) {
     if (lay.gh == ctx->g0 && lay.gw == ctx->g0) {

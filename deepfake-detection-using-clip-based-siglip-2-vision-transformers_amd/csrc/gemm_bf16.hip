@@ -103,7 +103,10 @@ __device__ __forceinline__ void store_tile(char* smem, f32x4 (&acc)[4][4], int w
         float s = 0.f;
 #pragma unroll
         for (int gI = 0; gI < GROUPS; ++gI) s += ct[gI * G_BN + t];
-        atomicAdd(p.colsum + n0 + t, s);
+        if (p.colsum_ld > 0)
+          p.colsum[(size_t)(m0 >> 7) * p.colsum_ld + n0 + t] = s;
+        else
+          atomicAdd(p.colsum + n0 + t, s);
       }
     }
   }
@@ -302,7 +305,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16* __restrict_
     if (kt + 1 < nk) store_stage(cur ^ 1);
     __syncthreads();
   }
-  store_tile<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, p);
+  EpiParams pq = p;
+  if (p.split_stride) pq.out = reinterpret_cast<float*>(p.out) + (size_t)blockIdx.y * p.split_stride;  // private slab
+  store_tile<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, pq);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -367,7 +372,7 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
 }
 
 hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mred, int N1, int N2, int splits,
-                        const EpiParams& p_, hipStream_t s) {
+                        const EpiParams& p_, hipStream_t s, float* split_ws, size_t split_ws_bytes) {
   if (N1 == 0 || N2 == 0) return hipSuccess;
   if ((lda % 8) || (ldb % 8)) return hipErrorInvalidValue;
   if ((size_t)Mred * lda * 2 >= (1ull << 32) || (size_t)Mred * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
@@ -396,6 +401,20 @@ hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mr
     mp = ((mp + G_BK - 1) / G_BK) * G_BK;
     sp = (Mred + mp - 1) / mp;
     if (sp > 1) {
+      const size_t slab = (size_t)N1 * N2;
+      if (split_ws && (size_t)sp * slab * sizeof(float) <= split_ws_bytes && p.alpha == 1.0f && !p.bias &&
+          (N2 % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)out) | ((uintptr_t)split_ws)) & 15) == 0) {
+        // deterministic split-K: private slabs + a fixed-order reduction (also ~4x cheaper than the atomic epilogue)
+        EpiParams q = p;
+        q.out = split_ws;
+        q.ldo = N2;
+        q.accumulate = 0;
+        q.atomic = 0;
+        q.split_stride = slab;
+        hipError_t e = gemm_tn2_bf16(A_, lda, B_, ldb, Mred, N1, N2, mp, sp, q, s);
+        if (e != hipSuccess) return e;
+        return reduce_splits(split_ws, sp, slab, N1, N2, out, p.ldo, p.accumulate, s);
+      }
       if (!p.accumulate) {
         hipError_t e = hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
         if (e != hipSuccess) return e;
@@ -408,14 +427,29 @@ hipError_t gemm_tn_bf16(const void* A_, int lda, const void* B_, int ldb, int Mr
   int m_per = (Mred + splits - 1) / splits;
   m_per = ((m_per + G_BK - 1) / G_BK) * G_BK;
   splits = (Mred + m_per - 1) / m_per;
+  const int tiles = ((N1 + G_BM - 1) / G_BM) * ((N2 + G_BN - 1) / G_BN);
   if (splits > 1) {
+    const size_t slab = (size_t)N1 * N2;
+    if (split_ws && (size_t)splits * slab * sizeof(float) <= split_ws_bytes && p.alpha == 1.0f && !p.bias &&
+        (N2 % 4 == 0) && (p.ldo % 4 == 0) && ((((uintptr_t)out) | ((uintptr_t)split_ws)) & 15) == 0) {
+      EpiParams q = p;  // deterministic split-K, as in the 256x256 path above
+      q.out = split_ws;
+      q.ldo = N2;
+      q.accumulate = 0;
+      q.atomic = 0;
+      q.split_stride = slab;
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), G_LDS, s, (const bf16*)A_, lda,
+                         (const bf16*)B_, ldb, Mred, N1, N2, m_per, q);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      return reduce_splits(split_ws, splits, slab, N1, N2, out, p.ldo, p.accumulate, s);
+    }
     if (!p.accumulate) {
       hipError_t e = hipMemset2DAsync(out, (size_t)p.ldo * sizeof(float), 0, (size_t)N2 * sizeof(float), N1, s);
       if (e != hipSuccess) return e;
     }
     p.atomic = 1;
   }
-  const int tiles = ((N1 + G_BM - 1) / G_BM) * ((N2 + G_BN - 1) / G_BN);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), G_LDS, s, (const bf16*)A_, lda, (const bf16*)B_,
                      ldb, Mred, N1, N2, m_per, p);
   return hipGetLastError();

@@ -126,7 +126,10 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
         float s = 0.f;
 #pragma unroll
         for (int gI = 0; gI < GROUPS; ++gI) s += ct[gI * T_BN + t];
-        atomicAdd(p.colsum + n0 + t, s);
+        if (p.colsum_ld > 0)
+          p.colsum[(size_t)(m0 >> 7) * p.colsum_ld + n0 + t] = s;
+        else
+          atomicAdd(p.colsum + n0 + t, s);
       }
     }
   }
@@ -524,7 +527,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn6_kernel(const bf16* __restrict
 #undef SGL_TR6
   if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
-  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, p);
+  EpiParams pq = p;
+  if (p.split_stride) pq.out = reinterpret_cast<float*>(p.out) + (size_t)split * p.split_stride;  // private slab of this split
+  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, pq);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -615,7 +620,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict
       sched_pipeline<2>();
     }
   }
-  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, p);
+  EpiParams pq = p;
+  if (p.split_stride) pq.out = reinterpret_cast<float*>(p.out) + (size_t)split * p.split_stride;  // private slab of this split
+  store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, pq);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -35,6 +35,13 @@ struct EpiParams {
   // EPI_GELU_BWD on the MFMA kernels: when non-null, column sums of the fp32 output tile are atomically added here
   // (= the bias gradient of the GEMM whose output gradient is being produced); must be zeroed/initialised by the host
   float* colsum = nullptr;
+  // colsum_ld == 0: atomicAdd into colsum[col].  colsum_ld > 0 (deterministic): the workgroup whose tile starts at row m0
+  // STORES its column sums at colsum[(m0 / 128) * colsum_ld + col]; the host zeroes the [ceil(M/128)][colsum_ld] buffer
+  // first and folds the rows in a fixed order afterwards (reduce_partials)
+  int colsum_ld = 0;
+  // split-K TN GEMM, deterministic form: split s stores its partial tile at out + s*split_stride (plain stores, ldo = N2)
+  // instead of atomically adding into the result; reduce_splits() then sums the slabs in a fixed order
+  size_t split_stride = 0;
 };
 
 // ---- layernorm.hip -----------------------------------------------------------------------------------
@@ -87,8 +94,13 @@ hipError_t gemm_f32_generic(const float* A, long sam, long sak, const float* B, 
 hipError_t gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                         int out_dtype, const EpiParams& p, hipStream_t s);
 // TN: C[N1,N2] (+)= sum_m A[m,n1] * B[m,n2] ; fp32 output via EPI_F32 (accumulate / atomic split-K)
+// out[r*ldo + c] (+)= sum_s ws[s*stride + r*N2 + c]   (fixed summation order)
+hipError_t reduce_splits(const float* ws, int splits, size_t stride, int N1, int N2, float* out, int ldo, int accumulate,
+                         hipStream_t s);
+// split_ws (optional device scratch): when given and large enough, the splits of the 256x256-tile kernel write private
+// slabs and reduce_splits() sums them (bitwise reproducible); otherwise they add into `out` with fp32 atomics.
 hipError_t gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
-                        const EpiParams& p, hipStream_t s);
+                        const EpiParams& p, hipStream_t s, float* split_ws = nullptr, size_t split_ws_bytes = 0);
 
 // ---- attention.hip -------------------------------------------------------------------------------------
 // q,k,v: head-major [B][H][N][DP]; out: token-major [B*N][H*dh]; lse: [B][H][N] (natural log units)

@@ -224,3 +224,21 @@ def test_binary_and_video_models_run_on_hip_encoder(pkg, hiplib):
     with torch.no_grad():
         f = bb.encode_image(clips.view(8, 3, 32, 32))
         assert torch.allclose(vid(clips), vid.head(f, batch_size=2), atol=1e-6)
+
+
+@pytest.mark.parametrize("batch", [2, 4])   # 2: small-M GEMM generation with two splits; 4: 256x256-tile generation
+def test_backward_is_bitwise_reproducible(batch, pkg, hiplib):
+    """Every kernel on the training path has a fixed summation order (split-K dW GEMMs write private slabs that are
+    reduced in order; no fp32 atomics into gradients), so two runs on the same inputs give identical bits."""
+    cfg = pkg.get_config("so400m-1layer")          # full-width block: the dW GEMMs take the 256x256 split-K path
+    model = build(pkg, "so400m-1layer", 4, "bf16")
+    x = pkg.weights.seeded_pixels(batch, cfg.image_size, cfg.image_size, seed=9).cuda()
+    runs = []
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = None
+        out = model(pixel_values=x, interpolate_pos_encoding=True)
+        (out.pooler_output.square().mean() + out.last_hidden_state.mean()).backward()
+        runs.append({n: p.grad.clone() for n, p in model.named_parameters()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
