@@ -162,8 +162,17 @@ class _EncoderFn(torch.autograd.Function):
             ctx.tap_ids, ctx.want_pooled, ctx.weights, ctx.shadow = tap_ids, want_pooled, weights, shadow
         outs = [pooled if want_pooled else last.new_zeros(()), last.view(B, N, D)]
         outs += [hs[i].view(B, N, D) for i in tap_ids]
-        if not want_pooled:
-            ctx.mark_non_differentiable(outs[0])
+        dead = [] if want_pooled else [outs[0]]
+        if train:
+            # hidden_states[i] only feeds gradient to the embeddings and to blocks < i: with those frozen
+            # (Siglip2sidafrozen.py:757-768) the tap's gradient would be computed by the consumer (the SID decoder's
+            # tap projections) and then dropped here, so tell autograd not to ask for it
+            trainable = {grp for (grp, _), p in zip(mod._flat_names, params) if p.requires_grad}
+            if "emb" not in trainable:
+                first = min([int(g_[5:]) for g_ in trainable if g_.startswith("layer")] or [L])
+                dead += [t for i, t in zip(tap_ids, outs[2:]) if i <= first]
+        if dead:
+            ctx.mark_non_differentiable(*dead)
         return tuple(outs)
 
     @staticmethod

@@ -65,18 +65,49 @@ class SegFormerMaskDecoder(nn.Module):
         self.head = nn.Conv2d(embed_dim, 1, 1)
         self.head_before_upsample = head_before_upsample
 
+    @staticmethod
+    def _pointwise(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+        """A 1x1 convolution on token-major data (..., C_in) -> (..., C_out): a plain GEMM (hipBLASLt) instead of a
+        MIOpen convolution; the parameters keep their Conv2d shapes, so checkpoints are unchanged."""
+        return F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+
+    @staticmethod
+    def _depthwise3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+        """Depthwise 3x3, zero padding 1, on channels-last data (B, gh, gw, E): nine shifted multiply-adds (the same
+        arithmetic as nn.Conv2d(E, E, 3, padding=1, groups=E); MIOpen has only a naive fp32 NHWC solver for it)."""
+        w = conv.weight                      # (E, 1, 3, 3)
+        xp = F.pad(x, (0, 0, 1, 1, 1, 1))    # pad gw and gh by one
+        gh, gw = x.shape[1], x.shape[2]
+        out = None
+        for dy in range(3):
+            for dx in range(3):
+                term = xp[:, dy:dy + gh, dx:dx + gw, :] * w[:, 0, dy, dx]
+                out = term if out is None else out + term
+        return out + conv.bias if conv.bias is not None else out
+
     def forward(self, hidden_list: Sequence[torch.Tensor], grid_hw: Tuple[int, int], target_size: int = 448):
+        """Everything up to the 1-channel logit map runs token-major / channels-last as GEMMs and elementwise ops (same
+        math as the reference's NCHW convolutions, Siglip2sidafrozen.py:726-745); only the final bilinear up-sample of
+        the (B,1,g,g) logits uses an NCHW tensor."""
         gh, gw = grid_hw
         feats = []
         for proj, smooth, h in zip(self.projs, self.smooth, hidden_list):
-            x = proj(h).transpose(1, 2)
-            b, e, _ = x.shape
-            feats.append(smooth(x.reshape(b, e, gh, gw)))
-        x = torch.cat(feats, dim=1)
-        x = self.fuse(self.fuse_attn(x) * x)
+            x = proj(h)                                              # (B, N, E)
+            b, _, e = x.shape
+            x = self._depthwise3x3(smooth[0], x.reshape(b, gh, gw, e))
+            x = F.gelu(self._pointwise(smooth[1], x))
+            for extra in list(smooth)[3:]:                           # Dropout2d when configured: acts on channels
+                x = extra(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            feats.append(x)
+        x = torch.cat(feats, dim=-1)                                 # (B, gh, gw, E*K)
+        gate = torch.sigmoid(self._pointwise(self.fuse_attn[2], F.gelu(self._pointwise(self.fuse_attn[0], x))))
+        x = self._pointwise(self.fuse[0], gate * x)
+        for extra in list(self.fuse)[1:]:
+            x = extra(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
         if self.head_before_upsample:
-            return F.interpolate(self.head(x), size=(target_size, target_size), mode="bilinear", align_corners=False)
-        x = F.interpolate(x, size=(target_size, target_size), mode="bilinear", align_corners=False)
+            logit = self._pointwise(self.head, x).permute(0, 3, 1, 2)   # (B, 1, gh, gw)
+            return F.interpolate(logit, size=(target_size, target_size), mode="bilinear", align_corners=False)
+        x = F.interpolate(x.permute(0, 3, 1, 2), size=(target_size, target_size), mode="bilinear", align_corners=False)
         return self.head(x)
 
 
