@@ -37,6 +37,56 @@ class _TapProj(nn.Module):
         return self.proj(x)
 
 
+class _DepthwiseConv3x3Fn(torch.autograd.Function):
+    """Depthwise 3x3 (padding 1) on channels-last (B, gh, gw, E) CUDA tensors through the HIP kernels of
+    csrc/decoder.hip: forward, data gradient (same stencil, flipped taps) and the two-stage weight/bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import lib as _lib
+        lib = _lib.load()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        B, gh, gw, E = x.shape
+        y = torch.empty_like(x)
+        dt = _lib.SGL_DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.SGL_DTYPE_F32
+        _lib.check(lib.sgl_op_dwconv3x3(x.data_ptr(), dt, w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, gh, gw, E, 0,
+                                        _lib.current_stream_handle()), "sgl_op_dwconv3x3")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.wdtype = weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as _lib
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        B, gh, gw, E = x.shape
+        dt = _lib.SGL_DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.SGL_DTYPE_F32
+        stream = _lib.current_stream_handle()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.sgl_op_dwconv3x3(dy.data_ptr(), dt, w.data_ptr(), None, dx.data_ptr(), B, gh, gw, E, 1, stream),
+                       "sgl_op_dwconv3x3(flip)")
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(E, 1, 3, 3, device=x.device, dtype=torch.float32)
+            db = torch.empty(E, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            nbytes = lib.sgl_op_dwconv3x3_wgrad_scratch_bytes(B, gh, gw, E)
+            scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+            _lib.check(lib.sgl_op_dwconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dt, dw.data_ptr(), _lib.ptr(db), 0,
+                                                  scratch.data_ptr(), nbytes, B, gh, gw, E, stream),
+                       "sgl_op_dwconv3x3_wgrad")
+            dw = dw.to(ctx.wdtype)
+        return dx, dw, db
+
+
 class SegFormerMaskDecoder(nn.Module):
     """SegFormer-style mask decoder (`SegFormerStrongDecoder`, Siglip2sidafrozen.py:698-745).
 
@@ -75,6 +125,9 @@ class SegFormerMaskDecoder(nn.Module):
     def _depthwise3x3(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
         """Depthwise 3x3, zero padding 1, on channels-last data (B, gh, gw, E): nine shifted multiply-adds (the same
         arithmetic as nn.Conv2d(E, E, 3, padding=1, groups=E); MIOpen has only a naive fp32 NHWC solver for it)."""
+        e = x.shape[-1]
+        if x.is_cuda and e % 4 == 0 and e <= 1024 and 256 % (e // 4) == 0:
+            return _DepthwiseConv3x3Fn.apply(x, conv.weight, conv.bias)   # one HBM pass (csrc/decoder.hip)
         w = conv.weight                      # (E, 1, 3, 3)
         xp = F.pad(x, (0, 0, 1, 1, 1, 1))    # pad gw and gh by one
         gh, gw = x.shape[1], x.shape[2]

@@ -282,3 +282,25 @@ def test_colsum_im2col_posresize(lib, oracle):
         ref = torch.nn.functional.interpolate(t.view(1, g0, g0, 40).permute(0, 3, 1, 2), size=(gh, gh), mode="bicubic",
                                               align_corners=False).permute(0, 2, 3, 1).reshape(gh * gh, 40)
         assert (o - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,gh,gw,E", [(3, 27, 27, 256), (2, 5, 7, 64), (1, 1, 1, 128), (2, 3, 9, 4)])
+@pytest.mark.parametrize("tdt", [torch.float32, torch.bfloat16])
+def test_depthwise_conv3x3_fwd_and_grads(B, gh, gw, E, tdt):
+    """csrc/decoder.hip against the operator it replaces: nn.Conv2d(E, E, 3, padding=1, groups=E)
+    (Siglip2sidafrozen.py:713-718) in fp32 on the same (bf16-rounded) inputs."""
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    torch.manual_seed(B * 100 + E)
+    conv = torch.nn.Conv2d(E, E, 3, padding=1, groups=E).cuda()
+    x = torch.randn(B, gh, gw, E, device="cuda").to(tdt).requires_grad_(True)
+    dy = torch.randn(B, gh, gw, E, device="cuda").to(tdt)
+    y = pkg.heads._DepthwiseConv3x3Fn.apply(x, conv.weight, conv.bias)
+    assert y.dtype == tdt
+    gx, gw_, gb = torch.autograd.grad(y, [x, conv.weight, conv.bias], dy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = conv(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    rx, rw, rb = torch.autograd.grad(yr, [xr, conv.weight, conv.bias], dy.float())
+    tol = 2e-5 if tdt == torch.float32 else 1.2e-2
+    assert relerr(y, yr) < tol and relerr(gx, rx) < tol
+    assert relerr(gw_, rw) < (1e-4 if tdt == torch.float32 else 1.2e-2) and relerr(gb, rb) < (1e-4 if tdt == torch.float32 else 1.2e-2)
