@@ -267,9 +267,12 @@ def main():
         pkg.GradBucketReducer().attach(model)
     x = pkg.weights.seeded_pixels(args.batch, res, res, seed=1234 + rank).to(dev)
     params = [p for p in model.parameters()]
+    trainable = [p for p in params if p.requires_grad]
 
     def step():
-        model._shadow_key = None  # weights "changed" (optimizer step) -> refresh bf16 shadows, as autocast would
+        # an optimizer step happened: every trainable parameter changed, so its bf16 shadows are re-cast in this step
+        # (what autocast re-does per step in the reference, Siglip2sidafrozen.py:1375); frozen tensors keep theirs
+        torch.autograd.graph.increment_version(trainable)
         out = model(pixel_values=x, interpolate_pos_encoding=True)
         loss = out.pooler_output.square().mean()
         loss.backward()

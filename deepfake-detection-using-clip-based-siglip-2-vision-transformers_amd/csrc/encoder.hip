@@ -283,13 +283,19 @@ int sgl_query_sizes(const sgl_ctx* ctx, int B, int H, int W, int train, size_t* 
   return SGL_OK;
 }
 
-int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes, sgl_stream stream) {
+// layer_dirty: L flags (NULL = every block); globals_dirty: patch embedding + pooling-head matrices.  Frozen-prefix
+// fine-tuning (Siglip2sidafrozen.py:757-768) changes 6 of 27 blocks per step: re-casting all of them every step was
+// 2.5 % of that config's step.
+int sgl_prepare_weights_dirty(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes,
+                              const unsigned char* layer_dirty, int globals_dirty, sgl_stream stream) {
   if (!ctx || !w || !shadow || (ctx->L > 0 && !w->layers)) return SGL_ERR_NULL;
   if (shadow_bytes < ctx->sh_total) return SGL_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, dt = ctx->dt;
-  CK(cast_pad(w->patch_w, D, ctx->K0, ctx->K0, at(shadow, ctx->sh_wpatch), dt, D, ctx->Kp, ctx->Kp, s));
+  if (globals_dirty)
+    CK(cast_pad(w->patch_w, D, ctx->K0, ctx->K0, at(shadow, ctx->sh_wpatch), dt, D, ctx->Kp, ctx->Kp, s));
   for (int l = 0; l < ctx->L; ++l) {
+    if (layer_dirty && !layer_dirty[l]) continue;
     const sgl_layer_weights& lw = w->layers[l];
     const ShadowLayer& sl = ctx->sh_layers[l];
     const float* qkv_w[3] = {lw.q_w, lw.k_w, lw.v_w};
@@ -307,7 +313,7 @@ int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t
     CK(cast_transpose_pad(lw.fc2_w, D, I, I, at(shadow, sl.w2_t), dt, Ip, D, D, s));
     CK(cast_pad(lw.fc1_b, 1, I, I, at(shadow, sl.b1), DT_F32, 1, Ip, Ip, s));
   }
-  if (ctx->cfg.use_head) {
+  if (ctx->cfg.use_head && globals_dirty) {
     const float* kv_w = w->in_proj_w + (size_t)D * D;
     CK(cast_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv), dt, 2 * D, D, D, s));
     CK(cast_transpose_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv_t), dt, D, 2 * D, 2 * D, s));
@@ -320,6 +326,10 @@ int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t
     CK(cast_pad(w->head_fc1_b, 1, I, I, at(shadow, ctx->sh_hb1), DT_F32, 1, Ip, Ip, s));
   }
   return SGL_OK;
+}
+
+int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes, sgl_stream stream) {
+  return sgl_prepare_weights_dirty(ctx, w, shadow, shadow_bytes, nullptr, 1, stream);
 }
 
 // -------------------------------------------------------------------------------------------------------

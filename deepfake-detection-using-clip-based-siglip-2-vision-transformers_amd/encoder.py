@@ -452,19 +452,31 @@ class SiglipVisionModelHIP(nn.Module):
         if params[0].device != dev:
             raise RuntimeError(f"model is on {params[0].device}, input on {dev}")
         ptr_key = tuple(p.data_ptr() for p in params)
-        ver_key = tuple(p._version for p in params)
         if self._weights_struct is None or self._weights_key != ptr_key:
             self._weights_struct, self._weights_keep = self._build_weights_struct(params)
             self._weights_key = ptr_key
-        key = (ptr_key, ver_key)
-        if self._shadow is None or self._shadow.device != dev or self._shadow_key != key:
+        # one (pointers, versions) key per block and one for everything else: only what changed is re-cast, so a
+        # frozen-prefix run (Siglip2sidafrozen.py:757-768) refreshes its 6 trainable blocks, not all 27
+        L = self.config.num_hidden_layers
+        keys = [[] for _ in range(L + 1)]
+        for (grp, _), p in zip(self._flat_names, params):
+            keys[int(grp[5:]) if grp.startswith("layer") else L].append((p.data_ptr(), p._version))
+        keys = [tuple(k) for k in keys]
+        fresh = self._shadow is None or self._shadow.device != dev or self._shadow_key is None
+        if fresh or self._shadow_key != keys:
             nbytes = self._sizes(1, self.config.patch_size, self.config.patch_size, False)[0]
             if self._shadow is None or self._shadow.device != dev or self._shadow.numel() < nbytes:
                 self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            st = lib.sgl_prepare_weights(self._ctx, C.byref(self._weights_struct), self._shadow.data_ptr(),
-                                         self._shadow.numel(), _lib.current_stream_handle())
-            _lib.check(st, "sgl_prepare_weights", self._ctx)
-            self._shadow_key = key
+                fresh = True
+            if fresh:
+                dirty, glob = None, 1
+            else:
+                dirty = bytes(1 if keys[l] != self._shadow_key[l] else 0 for l in range(L))
+                glob = 1 if keys[L] != self._shadow_key[L] else 0
+            st = lib.sgl_prepare_weights_dirty(self._ctx, C.byref(self._weights_struct), self._shadow.data_ptr(),
+                                               self._shadow.numel(), dirty, glob, _lib.current_stream_handle())
+            _lib.check(st, "sgl_prepare_weights_dirty", self._ctx)
+            self._shadow_key = keys
         return self._shadow, self._weights_struct
 
     def _apply(self, fn, *a, **kw):

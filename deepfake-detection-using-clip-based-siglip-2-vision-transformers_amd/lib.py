@@ -92,6 +92,7 @@ def load():
     _sig(lib, "sgl_last_hip_error", i, [C.c_void_p])
     _sig(lib, "sgl_query_sizes", i, [C.c_void_p, i, i, i, i, psz, psz, psz])
     _sig(lib, "sgl_prepare_weights", i, [C.c_void_p, C.POINTER(SglWeights), _fp, sz, _fp])
+    _sig(lib, "sgl_prepare_weights_dirty", i, [C.c_void_p, C.POINTER(SglWeights), _fp, sz, C.c_char_p, i, _fp])
     _sig(lib, "sgl_forward", i, [C.c_void_p, C.POINTER(SglWeights), _fp, _fp, i, i, i, i, i, _fp, i, _fp, _fp, _fp, sz,
                                  _fp, sz, _fp])
     _sig(lib, "sgl_backward_begin", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, _fp, _fp,

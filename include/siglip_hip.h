@@ -110,6 +110,10 @@ int sgl_query_sizes(const sgl_ctx* ctx, int B, int H, int W, int train, size_t* 
 /* Refresh the shadow arena from the fp32 masters (call after every optimizer step / load_state_dict).
  * Replaces the per-step autocast weight casts of the reference (Siglip2sidafrozen.py:1375). */
 int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes, sgl_stream stream);
+/* Same, restricted to what changed since the last call: layer_dirty[l] != 0 re-casts block l (NULL = all blocks),
+ * globals_dirty != 0 re-casts the patch-embedding and pooling-head matrices.  For frozen-prefix fine-tuning. */
+int sgl_prepare_weights_dirty(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t shadow_bytes,
+                              const unsigned char* layer_dirty, int globals_dirty, sgl_stream stream);
 
 /* ---- forward ---------------------------------------------------------------------------------------- */
 /* pixels: fp32 (B,3,H,W) NCHW, or NHWC storage when channels_last != 0 (reference .to(channels_last),

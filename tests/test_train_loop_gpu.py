@@ -10,8 +10,9 @@ import __graft_entry__ as entry
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("freeze_below", [0, 1])   # 1: embeddings + block 0 frozen (only the dirty blocks are re-cast)
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
-def test_three_training_steps_track_the_cpu_reference(mode, tol):
+def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below):
     pkg, oracle = entry.load_package(), entry.load_oracle()
     cfg = pkg.get_config("hostile")
     sd0 = pkg.weights.seeded_state_dict(cfg, seed=11)
@@ -20,15 +21,18 @@ def test_three_training_steps_track_the_cpu_reference(mode, tol):
     lr, wd, clip = 2e-3, 0.05, 0.5
 
     # CPU reference loop
-    ref = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
-    ropt = torch.optim.AdamW(list(ref.values()), lr=lr, weight_decay=wd)
+    def frozen(name):
+        return freeze_below > 0 and (name.startswith("embeddings.") or
+                                     any(name.startswith(f"encoder.layers.{i}.") for i in range(freeze_below)))
+    ref = {k: v.clone().requires_grad_(not frozen(k)) for k, v in sd0.items()}
+    ropt = torch.optim.AdamW([v for v in ref.values() if v.requires_grad], lr=lr, weight_decay=wd)
     ref_losses = []
     for _ in range(3):
         out = oracle.vision_forward(x, ref, cfg, False, True)
         loss = ((out["pooler_output"] - target) ** 2).mean() + 0.1 * out["last_hidden_state"].square().mean()
         ropt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(list(ref.values()), clip)
+        torch.nn.utils.clip_grad_norm_([v for v in ref.values() if v.requires_grad], clip)
         ropt.step()
         ref_losses.append(loss.item())
 
@@ -36,7 +40,9 @@ def test_three_training_steps_track_the_cpu_reference(mode, tol):
     model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
     model.load_state_dict(sd0)
     model = model.cuda()
-    opt = pkg.FusedAdamW(model.parameters(), lr=lr, weight_decay=wd, max_grad_norm=clip)
+    for n, p in model.named_parameters():
+        p.requires_grad = not frozen(n)
+    opt = pkg.FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd, max_grad_norm=clip)
     xd, td = x.cuda(), target.cuda()
     losses = []
     for _ in range(3):
@@ -56,6 +62,9 @@ def test_three_training_steps_track_the_cpu_reference(mode, tol):
     # with how far the tensor MOVED (Frobenius norms), not element by element.
     worst, who = 0.0, None
     for k, v in ref.items():
+        if not v.requires_grad:
+            assert torch.equal(got[k].cpu(), sd0[k]), k          # frozen tensors are untouched
+            continue
         if k.endswith("k_proj.bias"):
             # softmax is invariant to a per-query constant: d loss / d k_bias is exactly zero in exact arithmetic, so the
             # whole tensor is such noise
