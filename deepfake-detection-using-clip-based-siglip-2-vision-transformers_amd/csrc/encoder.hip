@@ -333,9 +333,24 @@ int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t
 }
 
 // -------------------------------------------------------------------------------------------------------
+int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
+                   int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
+                   float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
+                   sgl_stream stream);
+
 int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
                 int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
                 float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  return sgl_forward_ex(ctx, w, shadow, pixels, channels_last, B, H, W, interpolate_pos, hidden_states, hs_slots,
+                        last_hidden, pooled, saved, saved_bytes, ws, ws_bytes, 0, stream);
+}
+
+// first_trainable_block: blocks below it will never be differentiated (frozen prefix), so the forward does not write
+// their GELU pre-activations (406 MB per block at B = 64); inference (saved == NULL) never writes them.
+int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
+                   int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
+                   float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
+                   sgl_stream stream) {
   if (!ctx || !w || !shadow || !pixels || !hidden_states || !last_hidden) return SGL_ERR_NULL;
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   const bool train = saved != nullptr;
@@ -409,7 +424,7 @@ int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const fl
     CK(layernorm_fwd(xmid, lw.ln2_w, lw.ln2_b, lb + lay.r_h2, dt, D, st2, st2 + M, M, D, ctx->cfg.layer_norm_eps, s));
     {
       EpiParams p;
-      p.out = lb + lay.r_u;
+      p.out = (train && l >= first_trainable_block) ? lb + lay.r_u : nullptr;
       p.ldo = Ip;
       p.out2 = lb + lay.r_a;
       p.ldo2 = Ip;

@@ -33,7 +33,8 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
       v[j] += b[j];
       a[j] = gelu_tanh(v[j]);
     }
-    Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
+    // the pre-activation u is only read by the backward GELU': inference and frozen blocks pass out == nullptr
+    if (p.out) Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
     Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out2) + (size_t)row * p.ldo2 + col, a);
   } else if constexpr (EPI == EPI_RES_F32) {
     float b[NV], r[NV];

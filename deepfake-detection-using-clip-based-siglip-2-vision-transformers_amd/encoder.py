@@ -152,11 +152,17 @@ class _EncoderFn(torch.autograd.Function):
         pooled = torch.empty((B, D), dtype=torch.float32, device=dev) if want_pooled else None
         saved = torch.empty(sizes[1], dtype=torch.uint8, device=dev) if train else None
         ws = None if train else torch.empty(sizes[2], dtype=torch.uint8, device=dev)
-        st = lib.sgl_forward(mod._ctx, C.byref(weights), shadow.data_ptr(), px.data_ptr(), channels_last, B, H, W,
-                             1 if interp else 0, hs.data_ptr(), hs_slots, last.data_ptr(), _lib.ptr(pooled),
-                             _lib.ptr(saved), sizes[1] if train else 0, _lib.ptr(ws), 0 if train else sizes[2],
-                             _lib.current_stream_handle())
-        _lib.check(st, "sgl_forward", mod._ctx)
+        # first block that can receive a gradient (frozen prefix, Siglip2sidafrozen.py:757-768); 0 when the embeddings train
+        first = 0
+        if train:
+            trainable = {grp for (grp, _), p in zip(mod._flat_names, params) if p.requires_grad}
+            if "emb" not in trainable:
+                first = min([int(g_[5:]) for g_ in trainable if g_.startswith("layer")] or [L])
+        st = lib.sgl_forward_ex(mod._ctx, C.byref(weights), shadow.data_ptr(), px.data_ptr(), channels_last, B, H, W,
+                                1 if interp else 0, hs.data_ptr(), hs_slots, last.data_ptr(), _lib.ptr(pooled),
+                                _lib.ptr(saved), sizes[1] if train else 0, _lib.ptr(ws), 0 if train else sizes[2],
+                                first, _lib.current_stream_handle())
+        _lib.check(st, "sgl_forward_ex", mod._ctx)
         if train:
             ctx.mod, ctx.saved, ctx.hs, ctx.geom, ctx.interp = mod, saved, hs, (B, H, W, N, M), interp
             ctx.tap_ids, ctx.want_pooled, ctx.weights, ctx.shadow = tap_ids, want_pooled, weights, shadow
@@ -167,9 +173,7 @@ class _EncoderFn(torch.autograd.Function):
             # hidden_states[i] only feeds gradient to the embeddings and to blocks < i: with those frozen
             # (Siglip2sidafrozen.py:757-768) the tap's gradient would be computed by the consumer (the SID decoder's
             # tap projections) and then dropped here, so tell autograd not to ask for it
-            trainable = {grp for (grp, _), p in zip(mod._flat_names, params) if p.requires_grad}
             if "emb" not in trainable:
-                first = min([int(g_[5:]) for g_ in trainable if g_.startswith("layer")] or [L])
                 dead += [t for i, t in zip(tap_ids, outs[2:]) if i <= first]
         if dead:
             ctx.mark_non_differentiable(*dead)

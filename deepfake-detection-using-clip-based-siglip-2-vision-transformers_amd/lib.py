@@ -95,6 +95,8 @@ def load():
     _sig(lib, "sgl_prepare_weights_dirty", i, [C.c_void_p, C.POINTER(SglWeights), _fp, sz, C.c_char_p, i, _fp])
     _sig(lib, "sgl_forward", i, [C.c_void_p, C.POINTER(SglWeights), _fp, _fp, i, i, i, i, i, _fp, i, _fp, _fp, _fp, sz,
                                  _fp, sz, _fp])
+    _sig(lib, "sgl_forward_ex", i, [C.c_void_p, C.POINTER(SglWeights), _fp, _fp, i, i, i, i, i, _fp, i, _fp, _fp, _fp, sz,
+                                    _fp, sz, i, _fp])
     _sig(lib, "sgl_backward_begin", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, _fp, _fp,
                                         _fp, _fp, _fp, sz, _fp, sz, _fp])
     _sig(lib, "sgl_backward_layer", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, i, _fp,

@@ -127,6 +127,12 @@ int sgl_prepare_weights_dirty(sgl_ctx* ctx, const sgl_weights* w, void* shadow, 
 int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
                 int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
                 float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+/* sgl_forward with a frozen prefix declared: blocks < first_trainable_block will not be differentiated
+ * (sgl_backward_layer is never called for them), so their GELU pre-activations are not saved. */
+int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
+                   int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
+                   float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
+                   sgl_stream stream);
 
 /* ---- backward (stepwise so that a data-parallel caller can all-reduce each block's gradients while the
  *      next block's backward runs; sgl_backward is the plain loop over the three steps) ------------------ */
