@@ -48,9 +48,9 @@ class _DepthwiseConv3x3Fn(torch.autograd.Function):
         if x.dtype not in (torch.float32, torch.bfloat16):
             x = x.float()
         x = x.contiguous()
-        w = weight.detach().float().contiguous()
-        b = None if bias is None else bias.detach().float().contiguous()
         B, gh, gw, E = x.shape
+        w = weight.detach().float().reshape(E, 9).t().contiguous()      # tap-major [9][E] (see siglip_hip.h)
+        b = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty_like(x)
         dt = _lib.SGL_DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.SGL_DTYPE_F32
         _lib.check(lib.sgl_op_dwconv3x3(x.data_ptr(), dt, w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, gh, gw, E, 0,
@@ -76,14 +76,14 @@ class _DepthwiseConv3x3Fn(torch.autograd.Function):
                        "sgl_op_dwconv3x3(flip)")
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty(E, 1, 3, 3, device=x.device, dtype=torch.float32)
-            db = torch.empty(E, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            dw10 = torch.empty(10, E, device=x.device, dtype=torch.float32)   # nine tap rows + the bias row
             nbytes = lib.sgl_op_dwconv3x3_wgrad_scratch_bytes(B, gh, gw, E)
             scratch = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-            _lib.check(lib.sgl_op_dwconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dt, dw.data_ptr(), _lib.ptr(db), 0,
+            _lib.check(lib.sgl_op_dwconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dt, dw10.data_ptr(), 0,
                                                   scratch.data_ptr(), nbytes, B, gh, gw, E, stream),
                        "sgl_op_dwconv3x3_wgrad")
-            dw = dw.to(ctx.wdtype)
+            dw = dw10[:9].t().reshape(E, 1, 3, 3).to(ctx.wdtype)
+            db = dw10[9] if ctx.has_bias else None
         return dx, dw, db
 
 
@@ -126,7 +126,7 @@ class SegFormerMaskDecoder(nn.Module):
         """Depthwise 3x3, zero padding 1, on channels-last data (B, gh, gw, E): nine shifted multiply-adds (the same
         arithmetic as nn.Conv2d(E, E, 3, padding=1, groups=E); MIOpen has only a naive fp32 NHWC solver for it)."""
         e = x.shape[-1]
-        if x.is_cuda and e % 4 == 0 and e <= 1024 and 256 % (e // 4) == 0:
+        if x.is_cuda and e % 8 == 0 and e <= 1024 and 256 % (e // 8) == 0 and 256 % (e // 4) == 0:
             return _DepthwiseConv3x3Fn.apply(x, conv.weight, conv.bias)   # one HBM pass (csrc/decoder.hip)
         w = conv.weight                      # (E, 1, 3, 3)
         xp = F.pad(x, (0, 0, 1, 1, 1, 1))    # pad gw and gh by one

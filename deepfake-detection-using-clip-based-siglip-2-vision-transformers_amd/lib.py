@@ -122,7 +122,7 @@ def load():
     _sig(lib, "sgl_op_ema", i, [_fp, _fp, i64, C.c_double, _fp])
     _sig(lib, "sgl_op_dwconv3x3", i, [_fp, i, _fp, _fp, _fp, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_dwconv3x3_wgrad_scratch_bytes", sz, [i, i, i, i])
-    _sig(lib, "sgl_op_dwconv3x3_wgrad", i, [_fp, _fp, i, _fp, _fp, i, _fp, sz, i, i, i, i, _fp])
+    _sig(lib, "sgl_op_dwconv3x3_wgrad", i, [_fp, _fp, i, _fp, i, _fp, sz, i, i, i, i, _fp])
     _lib = lib
     return lib
 

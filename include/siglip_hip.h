@@ -188,15 +188,16 @@ int sgl_op_pos_resize(const float* table, int native_grid, float* out, int gh, i
 /* ---- SID mask-decoder tail ---------------------------------------------------------------
  * Depthwise 3x3 convolution, zero padding 1, of SegFormerStrongDecoder's per-tap smoothing block
  * (nn.Conv2d(E, E, 3, padding=1, groups=E), Siglip2sidafrozen.py:713-718) on channels-last (B, gh, gw, E) data of
- * dtype f32 or bf16; w is the Conv2d weight [E][1][3][3] in fp32.  flip = 1 applies the 180-degree rotated taps (the
- * data gradient: dx = sgl_op_dwconv3x3(dy, w, NULL, flip = 1)).  E % 4 == 0, E <= 1024, 256 % (E/4) == 0. */
-int sgl_op_dwconv3x3(const void* x, int dtype, const float* w, const float* bias, void* y, int B, int gh, int gw, int E,
+ * dtype f32 or bf16.  w9 holds the nine taps TAP-MAJOR in fp32: w9[k*E + e] = Conv2d.weight[e][0][k/3][k%3].
+ * flip = 1 applies the 180-degree rotated taps (the data gradient: dx = sgl_op_dwconv3x3(dy, w9, NULL, flip = 1)).
+ * E % 8 == 0 (bf16) / E % 4 == 0 (f32), E <= 1024, 256 % (E / 8 or 4) == 0. */
+int sgl_op_dwconv3x3(const void* x, int dtype, const float* w9, const float* bias, void* y, int B, int gh, int gw, int E,
                      int flip, sgl_stream stream);
-/* dw[E][9] (+)= sum over pixels of x(shifted) * dy, dbias[E] (+)= sum dy (dbias may be NULL); two deterministic stages,
- * scratch >= sgl_op_dwconv3x3_wgrad_scratch_bytes(). */
+/* dw10[k*E + e] (+)= sum over pixels of x(shifted by tap k) * dy for k < 9, and dw10[9*E + e] (+)= sum dy (the bias
+ * gradient); two deterministic stages, scratch >= sgl_op_dwconv3x3_wgrad_scratch_bytes(). */
 size_t sgl_op_dwconv3x3_wgrad_scratch_bytes(int B, int gh, int gw, int E);
-int sgl_op_dwconv3x3_wgrad(const void* x, const void* dy, int dtype, float* dw, float* dbias, int accumulate,
-                           float* scratch, size_t scratch_bytes, int B, int gh, int gw, int E, sgl_stream stream);
+int sgl_op_dwconv3x3_wgrad(const void* x, const void* dy, int dtype, float* dw10, int accumulate, float* scratch,
+                           size_t scratch_bytes, int B, int gh, int gw, int E, sgl_stream stream);
 
 /* ---- optimizer step tail -----------------------------------------------------------------
  * Replaces, for a list of fp32 tensors, the reference's per-step pair

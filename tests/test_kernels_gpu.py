@@ -284,7 +284,7 @@ def test_colsum_im2col_posresize(lib, oracle):
         assert (o - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("B,gh,gw,E", [(3, 27, 27, 256), (2, 5, 7, 64), (1, 1, 1, 128), (2, 3, 9, 4)])
+@pytest.mark.parametrize("B,gh,gw,E", [(3, 27, 27, 256), (2, 27, 27, 512), (2, 5, 7, 64), (1, 1, 1, 128), (2, 3, 9, 8)])
 @pytest.mark.parametrize("tdt", [torch.float32, torch.bfloat16])
 def test_depthwise_conv3x3_fwd_and_grads(B, gh, gw, E, tdt):
     """csrc/decoder.hip against the operator it replaces: nn.Conv2d(E, E, 3, padding=1, groups=E)
