@@ -304,3 +304,28 @@ def test_depthwise_conv3x3_fwd_and_grads(B, gh, gw, E, tdt):
     tol = 2e-5 if tdt == torch.float32 else 1.2e-2
     assert relerr(y, yr) < tol and relerr(gx, rx) < tol
     assert relerr(gw_, rw) < (1e-4 if tdt == torch.float32 else 1.2e-2) and relerr(gb, rb) < (1e-4 if tdt == torch.float32 else 1.2e-2)
+
+
+@pytest.mark.parametrize("M,K,N", [(2916, 1152, 512), (729, 512, 512), (1458, 2048, 512), (300, 136, 72)])
+def test_hip_linear_function_matches_autocast_linear(M, K, N):
+    """heads._HipLinearFn (the decoder's GEMMs on the encoder's MFMA kernels) against what it replaces under autocast:
+    F.linear with bf16 operands, checked in fp32 on the same bf16-rounded inputs (forward, dX, dW, db)."""
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    torch.manual_seed(M + N)
+    lin = torch.nn.Linear(K, N).cuda()
+    x = torch.randn(M, K, device="cuda").bfloat16().requires_grad_(True)
+    dy = torch.randn(M, N, device="cuda").bfloat16()
+    y = pkg.heads._HipLinearFn.apply(x, lin.weight, lin.bias)
+    gx, gw, gb = torch.autograd.grad(y, [x, lin.weight, lin.bias], dy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = lin.weight.detach().bfloat16().float().requires_grad_(True)
+    yr = xr @ wr.t() + lin.bias
+    rx, rw, rb = torch.autograd.grad(yr, [xr, wr, lin.bias], dy.float())
+    assert y.dtype == torch.bfloat16 and relerr(y, yr) < 8e-3
+    assert relerr(gx, rx) < 8e-3 and relerr(gw, rw) < 8e-3 and relerr(gb, rb) < 8e-3
+    with torch.autocast("cuda", dtype=torch.bfloat16):       # the dispatcher picks the HIP path only under autocast
+        y2 = pkg.heads._linear_tokens(x.detach().reshape(1, M, K), lin.weight, lin.bias)
+    assert y2.shape == (1, M, N) and relerr(y2[0], yr) < 8e-3
+    if M >= 2048 and N >= 512 and K >= 512:
+        assert torch.equal(y2[0], y)                         # ... and only for shapes where it pays
