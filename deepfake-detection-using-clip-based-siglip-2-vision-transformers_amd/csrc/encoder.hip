@@ -862,10 +862,15 @@ int sgl_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, in
 
 int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
                    float* out, int ldo, int accumulate, sgl_stream stream) {
+  return sgl_op_gemm_tn_ws(dtype, A, lda, B, ldb, Mred, N1, N2, splits, out, ldo, accumulate, nullptr, 0, stream);
+}
+
+int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
+                      float* out, int ldo, int accumulate, float* scratch, size_t scratch_bytes, sgl_stream stream) {
   EpiParams p;
   p.out = out; p.ldo = ldo; p.accumulate = accumulate;
   if (dtype == DT_BF16)
-    CKV(gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, (hipStream_t)stream));
+    CKV(gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, (hipStream_t)stream, scratch, scratch_bytes));
   else
     CKV(gemm_f32_generic((const float*)A, 1, lda, (const float*)B, 1, ldb, N1, N2, Mred, EPI_F32, DT_F32, p,
                          (hipStream_t)stream));

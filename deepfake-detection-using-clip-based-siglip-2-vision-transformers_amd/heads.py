@@ -81,8 +81,10 @@ class _HipLinearFn(torch.autograd.Function):
             dx = dx.to(ctx.xdtype)
         if ctx.needs_input_grad[1]:   # dW[N,K] = dYᵀ · X
             dw = torch.empty(N, K, device=xb.device, dtype=torch.float32)
-            _lib.check(lib.sgl_op_gemm_tn(_lib.SGL_DTYPE_BF16, dyb.data_ptr(), N, xb.data_ptr(), K, M, N, K, 0,
-                                          dw.data_ptr(), K, 0, stream), "sgl_op_gemm_tn(dW)")
+            scratch = torch.empty(64 << 20, device=xb.device, dtype=torch.uint8)   # split-K slabs: deterministic sum
+            _lib.check(lib.sgl_op_gemm_tn_ws(_lib.SGL_DTYPE_BF16, dyb.data_ptr(), N, xb.data_ptr(), K, M, N, K, 0,
+                                             dw.data_ptr(), K, 0, scratch.data_ptr(), scratch.numel(), stream),
+                       "sgl_op_gemm_tn_ws(dW)")
             dw = dw.to(ctx.wdtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dyb.float().sum(0) if M < 64 else _hip_colsum(lib, _lib, dyb, M, N, stream)

@@ -110,6 +110,7 @@ def load():
     _sig(lib, "sgl_op_gemm_nt", i, [i, _fp, i, _fp, i, i, i, i, i, _fp, i, _fp, i, _fp, _fp, i, _fp, i, _fp, i, i, i,
                                     i, i, i, _fp])
     _sig(lib, "sgl_op_gemm_tn", i, [i, _fp, i, _fp, i, i, i, i, i, _fp, i, i, _fp])
+    _sig(lib, "sgl_op_gemm_tn_ws", i, [i, _fp, i, _fp, i, i, i, i, i, _fp, i, i, _fp, sz, _fp])
     _sig(lib, "sgl_op_attn_fwd", i, [i, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_attn_bwd", i, [i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_colsum", i, [i, _fp, i, i, i, _fp, i, _fp, sz, _fp])

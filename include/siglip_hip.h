@@ -174,6 +174,10 @@ int sgl_op_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, in
 /* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 output). */
 int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
                    float* out, int ldo, int accumulate, sgl_stream stream);
+/* Same with device scratch for the split-K partial tiles: with scratch >= splits_used * N1 * N2 * 4 bytes (64 MiB always
+ * suffices for the 256x256-tile kernel) the splits are summed in a fixed order -> bitwise reproducible, no fp32 atomics. */
+int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
+                      float* out, int ldo, int accumulate, float* scratch, size_t scratch_bytes, sgl_stream stream);
 int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
                     int head_dim, int head_dim_pad, sgl_stream stream);
 int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,

@@ -329,3 +329,24 @@ def test_hip_linear_function_matches_autocast_linear(M, K, N):
     assert y2.shape == (1, M, N) and relerr(y2[0], yr) < 8e-3
     if M >= 2048 and N >= 512 and K >= 512:
         assert torch.equal(y2[0], y)                         # ... and only for shapes where it pays
+
+
+def test_gemm_tn_with_scratch_is_reproducible_and_correct(lib):
+    """sgl_op_gemm_tn_ws: split-K partial tiles in caller scratch, summed in a fixed order -> same bits every run."""
+    torch.manual_seed(1)
+    Mred, N1, N2 = 6000, 1152, 512
+    A = torch.randn(Mred, N1, device="cuda").bfloat16()
+    B = torch.randn(Mred, N2, device="cuda").bfloat16()
+    scratch = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    outs = []
+    for _ in range(2):
+        out = torch.full((N1, N2), float("nan"), device="cuda")
+        ok(lib.sgl_op_gemm_tn_ws(BF16, P(A), N1, P(B), N2, Mred, N1, N2, 0, P(out), N2, 0, P(scratch), scratch.numel(),
+                                 torch.cuda.current_stream().cuda_stream))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(outs[0], A.float().t() @ B.float()) < 2e-3
+    acc = outs[0].clone()
+    ok(lib.sgl_op_gemm_tn_ws(BF16, P(A), N1, P(B), N2, Mred, N1, N2, 0, P(acc), N2, 1, P(scratch), scratch.numel(),
+                             torch.cuda.current_stream().cuda_stream))
+    assert relerr(acc, 2 * outs[0]) < 1e-6
