@@ -359,6 +359,8 @@ class SiglipVisionModelHIP(nn.Module):
             state_dict = weights_io.encoder_state_from_checkpoint(state_dict, self.config)
         return super().load_state_dict(dict(state_dict), strict=strict, **kw)
 
+    @torch.compiler.disable   # the reference torch.compile()s its models (cifake…:1888, hidf…:2922): Dynamo must not
+    # trace into the ctypes calls; the encoder is one opaque eager region and the graph breaks cleanly around it
     def forward(self, pixel_values, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
                 hidden_state_ids=None, **_):
         if pixel_values.device.type != "cuda":

@@ -91,6 +91,16 @@ class _HipLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+@torch.compiler.disable
+def _hip_linear(x2d, weight, bias):
+    return _HipLinearFn.apply(x2d, weight, bias)
+
+
+@torch.compiler.disable
+def _hip_dwconv(x, weight, bias):
+    return _DepthwiseConv3x3Fn.apply(x, weight, bias)
+
+
 def _hip_colsum(lib, _lib, t, M, N, stream):
     out = torch.empty(N, device=t.device, dtype=torch.float32)
     nbytes = ((M + 511) // 512 if (M + 511) // 512 < 256 else 256) * N * 4
@@ -109,7 +119,7 @@ def _linear_tokens(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
     if (_HIP_LINEAR and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
             and K % 8 == 0 and N % 8 == 0 and N >= 512 and K >= 512 and x.numel() // K >= 2048):
         # 256x256-tile kernels: worth it from 512 output columns (measured: E=512 decoder -5 %, E=256 decoder +5 % slower)
-        y = _HipLinearFn.apply(x.reshape(-1, K), weight, bias)
+        y = _hip_linear(x.reshape(-1, K), weight, bias)
         return y.reshape(*x.shape[:-1], N)
     return F.linear(x, weight, bias)
 
@@ -204,7 +214,7 @@ class SegFormerMaskDecoder(nn.Module):
         arithmetic as nn.Conv2d(E, E, 3, padding=1, groups=E); MIOpen has only a naive fp32 NHWC solver for it)."""
         e = x.shape[-1]
         if x.is_cuda and e % 8 == 0 and e <= 1024 and 256 % (e // 8) == 0 and 256 % (e // 4) == 0:
-            return _DepthwiseConv3x3Fn.apply(x, conv.weight, conv.bias)   # one HBM pass (csrc/decoder.hip)
+            return _hip_dwconv(x, conv.weight, conv.bias)   # one HBM pass (csrc/decoder.hip)
         w = conv.weight                      # (E, 1, 3, 3)
         xp = F.pad(x, (0, 0, 1, 1, 1, 1))    # pad gw and gh by one
         gh, gw = x.shape[1], x.shape[2]

@@ -242,3 +242,24 @@ def test_backward_is_bitwise_reproducible(batch, pkg, hiplib):
         runs.append({n: p.grad.clone() for n, p in model.named_parameters()})
     for n in runs[0]:
         assert torch.equal(runs[0][n], runs[1][n]), n
+
+
+def test_surrounding_model_can_be_torch_compiled(pkg, hiplib):
+    """The reference compiles its task models (cifake_binary_classifier.py:1888, hidf_video_classifier.py:2922).  The HIP
+    encoder is an opaque eager region for Dynamo (torch.compiler.disable), so torch.compile of the surrounding model must
+    run, match eager and back-propagate into the encoder."""
+    cfg = pkg.get_config("hostile")
+    enc = pkg.OpenClipStyleEncoder(cfg, "bf16")
+    enc.visual.load_state_dict(pkg.weights.seeded_state_dict(cfg, 0))
+    model = pkg.heads.FastBinaryClassifierHIP(enc, "small").cuda().eval()   # eval: no dropout noise in the comparison
+    x = pkg.weights.seeded_pixels(4, 42, 42, seed=1).cuda()
+    ref = model(x)
+    ref.sum().backward()
+    g0 = model.backbone.visual.head.probe.grad.clone()
+    for p in model.parameters():
+        p.grad = None
+    compiled = torch.compile(model)
+    out = compiled(x)
+    out.sum().backward()
+    assert torch.allclose(out, ref, atol=1e-5)
+    assert torch.allclose(model.backbone.visual.head.probe.grad, g0, atol=1e-5)
