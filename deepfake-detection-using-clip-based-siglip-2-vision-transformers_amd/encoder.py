@@ -435,8 +435,11 @@ class SiglipVisionModelHIP(nn.Module):
 
     def _build_weights_struct(self, params):
         L = self.config.num_hidden_layers
-        for p in params:
-            if p.dtype != torch.float32 or not p.is_contiguous():
+        for (grp, field), p in zip(self._flat_names, params):
+            # the 4-D patch-conv weight may be channels_last after model.to(memory_format=torch.channels_last)
+            # (Siglip2sidafrozen.py:1191): only the shadow refresh reads it, through a contiguous copy (_prepared)
+            strided_ok = field == "patch_w" and p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last)
+            if p.dtype != torch.float32 or not (p.is_contiguous() or strided_ok):
                 raise RuntimeError("encoder master parameters must be contiguous fp32 (the HIP path keeps its own "
                                    "bf16 shadows); do not call .half()/.bfloat16() on the encoder")
         layers = (_lib.SglLayerPtrs * max(L, 1))()
@@ -479,6 +482,10 @@ class SiglipVisionModelHIP(nn.Module):
             else:
                 dirty = bytes(1 if keys[l] != self._shadow_key[l] else 0 for l in range(L))
                 glob = 1 if keys[L] != self._shadow_key[L] else 0
+            pw = params[[f for _, f in self._flat_names].index("patch_w")]
+            if glob and not pw.is_contiguous():
+                self._patch_w_dense = pw.detach().contiguous()          # kept alive until the next refresh
+                self._weights_struct.patch_w = self._patch_w_dense.data_ptr()
             st = lib.sgl_prepare_weights_dirty(self._ctx, C.byref(self._weights_struct), self._shadow.data_ptr(),
                                                self._shadow.numel(), dirty, glob, _lib.current_stream_handle())
             _lib.check(st, "sgl_prepare_weights_dirty", self._ctx)

@@ -17,6 +17,12 @@ import torch
 from . import lib as _lib
 
 
+def _is_dense(t: torch.Tensor) -> bool:
+    """Storage holds exactly the tensor's elements, in some permutation (model.to(memory_format=channels_last) gives the
+    patch convolution's weight such a layout, Siglip2sidafrozen.py:1191)."""
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
 class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics (decoupled weight decay, bias correction, same operation order) in one launch
     for all tensors.  ``max_grad_norm`` > 0 folds ``clip_grad_norm_(all parameters, max_grad_norm)`` into the step: the
@@ -44,12 +50,12 @@ class FusedAdamW(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32:
                     raise RuntimeError("FusedAdamW handles fp32 CUDA parameters and gradients only (no CPU path)")
-                if not p.is_contiguous():
-                    raise RuntimeError("FusedAdamW needs contiguous parameters")
+                if not _is_dense(p):
+                    raise RuntimeError("FusedAdamW needs dense (contiguous or channels_last) parameters")
                 if p.grad.is_sparse:
                     raise RuntimeError("FusedAdamW does not support sparse gradients")
-                if not p.grad.is_contiguous():
-                    p.grad = p.grad.contiguous()
+                if p.grad.stride() != p.stride():   # the update is elementwise over storage: same layout everywhere
+                    p.grad = torch.empty_like(p).copy_(p.grad)
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0)
@@ -181,7 +187,7 @@ class ExponentialMovingAverage:
         if key != self._key:
             for p, s in ents:
                 if not (p.is_cuda and s.is_cuda and p.dtype == torch.float32 and s.dtype == torch.float32
-                        and p.is_contiguous() and s.is_contiguous()):
+                        and _is_dense(p) and s.stride() == p.stride()):
                     raise RuntimeError("ExponentialMovingAverage handles contiguous fp32 CUDA parameters only")
             dev = ents[0][0].device
             arr = (_lib.SglAdamwTensor * len(ents))()

@@ -10,9 +10,10 @@ import __graft_entry__ as entry
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("channels_last", [False, True])   # model and input as Siglip2sidafrozen.py:1191,1365 make them
 @pytest.mark.parametrize("freeze_below", [0, 1])   # 1: embeddings + block 0 frozen (only the dirty blocks are re-cast)
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
-def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below):
+def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below, channels_last):
     pkg, oracle = entry.load_package(), entry.load_oracle()
     cfg = pkg.get_config("hostile")
     sd0 = pkg.weights.seeded_state_dict(cfg, seed=11)
@@ -40,10 +41,15 @@ def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below):
     model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
     model.load_state_dict(sd0)
     model = model.cuda()
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        assert not model.embeddings.patch_embedding.weight.is_contiguous()
     for n, p in model.named_parameters():
         p.requires_grad = not frozen(n)
     opt = pkg.FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd, max_grad_norm=clip)
     xd, td = x.cuda(), target.cuda()
+    if channels_last:
+        xd = xd.to(memory_format=torch.channels_last)
     losses = []
     for _ in range(3):
         out = model(pixel_values=xd, interpolate_pos_encoding=True)
