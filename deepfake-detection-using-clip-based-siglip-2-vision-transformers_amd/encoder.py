@@ -552,6 +552,27 @@ class OpenClipStyleEncoder(nn.Module):
                   or k == prefix + "logit_bias"]:
             state_dict.pop(k)  # the text tower is never used on this path (train_fusion_head_only.py:115)
 
+    _HF_TO_TIMM = [("embeddings.patch_embedding.", "trunk.patch_embed.proj."),
+                   ("embeddings.position_embedding.weight", "trunk.pos_embed"),
+                   ("post_layernorm.", "trunk.norm."), ("head.probe", "trunk.attn_pool.latent"),
+                   ("head.attention.out_proj.", "trunk.attn_pool.proj."), ("head.attention.", "trunk.attn_pool."),
+                   ("head.layernorm.", "trunk.attn_pool.norm."), ("head.mlp.", "trunk.attn_pool.mlp."),
+                   (".layer_norm1.", ".norm1."), (".layer_norm2.", ".norm2."), (".self_attn.out_proj.", ".attn.proj."),
+                   (".self_attn.", ".attn."), ("encoder.layers.", "trunk.blocks.")]
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
+        """Parameter NAMES in open_clip/timm style (``visual.trunk.blocks.23.norm1.weight`` …): the reference selects what
+        to unfreeze by substring (``'blocks.23'``, ``'norm'``, simple_classifier.py:489-493).  q/k/v stay separate tensors
+        (``…attn.q_proj.weight``); the fused ``attn.qkv`` layout exists only in ``state_dict()``."""
+        root = prefix + ("." if prefix else "") + "visual."
+        for name, p in super().named_parameters(prefix=prefix, recurse=recurse, remove_duplicate=remove_duplicate):
+            if name.startswith(root):
+                tail = name[len(root):]
+                for a, b in self._HF_TO_TIMM:
+                    tail = tail.replace(a, b)
+                name = root + tail
+            yield name, p
+
     def encode_image(self, x, normalize: bool = False):
         out = self.visual(pixel_values=x, interpolate_pos_encoding=False)
         f = out.pooler_output

@@ -137,3 +137,23 @@ def test_adamw_plan_host_helper(hiplib):
     assert lib.sgl_adamw_plan(numel, 4, bm, nb) == nb
     assert list(bm) == [0, 0, 1, 0, 2, 0, 2, 1]
     assert lib.sgl_adamw_plan(None, 1, None, 0) < 0
+
+
+def test_open_clip_surface_parameter_names_support_the_reference_unfreezing(pkg):
+    """simple_classifier.py:484-493: freeze the backbone, then unfreeze by name substring ('blocks.<last>', 'norm', ...)."""
+    cfg = pkg.get_config("tiny")                      # 3 blocks
+    backbone = pkg.OpenClipStyleEncoder(cfg, "fp32")
+    names = [n for n, _ in backbone.named_parameters()]
+    assert "visual.trunk.blocks.2.mlp.fc1.weight" in names and "visual.trunk.norm.weight" in names
+    assert "visual.trunk.patch_embed.proj.weight" in names and "visual.trunk.pos_embed" in names
+    assert "visual.trunk.attn_pool.latent" in names and "visual.trunk.blocks.0.attn.q_proj.bias" in names
+    assert len(names) == len(list(backbone.parameters())) == len(set(names))
+    for p in backbone.parameters():
+        p.requires_grad = False
+    for n, p in backbone.named_parameters():
+        if any(x in n for x in ["blocks.2", "ln_final", "norm"]):
+            p.requires_grad = True
+    on = {n for n, p in backbone.named_parameters() if p.requires_grad}
+    assert all(("blocks.2." in n) or ("norm" in n) for n in on)
+    assert "visual.trunk.blocks.2.attn.proj.weight" in on and "visual.trunk.blocks.0.norm1.weight" in on
+    assert "visual.trunk.blocks.1.mlp.fc1.weight" not in on
