@@ -263,3 +263,17 @@ def test_surrounding_model_can_be_torch_compiled(pkg, hiplib):
     out.sum().backward()
     assert torch.allclose(out, ref, atol=1e-5)
     assert torch.allclose(model.backbone.visual.head.probe.grad, g0, atol=1e-5)
+
+
+def test_inference_mode_and_autocast_contexts(pkg, hiplib):
+    """Surface O/H callers wrap the encoder in torch.inference_mode() / no_grad() / autocast."""
+    model = build(pkg, "hostile", 2, "bf16").eval()
+    x = pkg.weights.seeded_pixels(2, 42, 42, seed=3).cuda()
+    with torch.no_grad():
+        a = model(pixel_values=x).pooler_output
+    with torch.inference_mode():
+        b = model(pixel_values=x).pooler_output
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        c = model(pixel_values=x.half()).pooler_output          # fp16 pixels as an autocast pipeline may hand them over
+    assert torch.equal(a, b) and a.dtype == torch.float32
+    assert torch.allclose(a, c, atol=2e-2)
