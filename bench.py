@@ -150,35 +150,38 @@ def optimizer_step_roofline(pkg, model, x, reps=10):
             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(32.0 * n / t / PEAK_HBM, 4)}
 
 
-def sustained_sclk_mhz(launch, seconds=2.0):
-    """Median rocm-smi sclk (MHz) over a few samples taken while `launch` is re-issued continuously; None when rocm-smi
-    is unavailable.  Informational: explains the distance between `peak` (datasheet, 2.4 GHz) and what the pool sustains."""
+def sustained_sclk_mhz(launch, max_seconds=8.0):
+    """Median rocm-smi sclk (MHz) over three samples, every one of them taken (call start to call end) while `launch` is
+    being re-issued back to back; None when rocm-smi is unavailable or too slow.  Informational: explains the distance
+    between `peak` (datasheet, 2.4 GHz) and what the pool sustains under MFMA load."""
     import re
     import subprocess
     import threading
-    samples, stop = [], [False]
+    samples, done = [], threading.Event()
 
     def probe():
-        while not stop[0]:
-            try:
+        try:
+            for i in range(4):
                 r = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
                 m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", r)
-                if m:
+                if m and i > 0:          # the first call may have started before the load did
                     samples.append(int(m.group(1)))
-            except Exception:
-                return
-            time.sleep(0.2)
+        except Exception:
+            pass
+        done.set()
+    for _ in range(20):
+        launch()
     th = threading.Thread(target=probe, daemon=True)
     t0 = time.perf_counter()
     th.start()
-    while time.perf_counter() - t0 < seconds:
+    while not done.is_set() and time.perf_counter() - t0 < max_seconds:
         for _ in range(20):
             launch()
         torch.cuda.synchronize()
-    stop[0] = True
+    ok = done.is_set()       # samples are valid only if the load outlasted the probe
     th.join(timeout=15)
-    samples = sorted(samples[1:] if len(samples) > 2 else samples)   # the first sample may predate the load
-    return samples[len(samples) // 2] if samples else None
+    samples.sort()
+    return samples[len(samples) // 2] if (ok and samples) else None
 
 
 def host_cores() -> int:
