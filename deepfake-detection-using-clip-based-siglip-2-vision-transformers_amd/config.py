@@ -119,6 +119,8 @@ NAMED_CONFIGS: dict[str, dict] = {
                     image_size=42, patch_size=14),
     "so400m-1layer": dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=1,
                           num_attention_heads=16, image_size=384, patch_size=14),
+    "base-1layer": dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=1,
+                        num_attention_heads=12, image_size=224, patch_size=16),
 }
 
 

@@ -51,6 +51,8 @@ struct sgl_ctx {
 
 namespace {
 
+constexpr int kMaxLayers = 128;
+
 // splits * N1 * N2 * 4 bytes with tiles*splits <= 256 workgroups of 256x256 outputs: never more than 64 MiB
 constexpr size_t kSplitWsBytes = (size_t)256 * 256 * 256 * 4;
 
@@ -198,7 +200,7 @@ bool shape_ok(const sgl_ctx* c, int B, int H, int W) {
 // =======================================================================================================
 extern "C" {
 
-int sgl_abi_version(void) { return 1; }
+int sgl_abi_version(void) { return 2; }
 
 const char* sgl_status_string(int status) {
   switch (status) {
@@ -217,7 +219,8 @@ sgl_ctx* sgl_create(const sgl_config* cfg) {
   if (cfg->hidden_size <= 0 || cfg->num_heads <= 0 || cfg->hidden_size % cfg->num_heads) return nullptr;
   const int dh = cfg->hidden_size / cfg->num_heads;
   if (dh % 8 || dh > 96 || cfg->hidden_size % 8 || cfg->hidden_size > 2048) return nullptr;
-  if (cfg->intermediate_size <= 0 || cfg->num_layers < 0 || cfg->patch_size <= 0 || cfg->native_grid <= 0)
+  if (cfg->intermediate_size <= 0 || cfg->num_layers < 0 || cfg->num_layers > 128 || cfg->patch_size <= 0 ||
+      cfg->native_grid <= 0)
     return nullptr;
   if (cfg->compute_dtype != SGL_DTYPE_F32 && cfg->compute_dtype != SGL_DTYPE_BF16) return nullptr;
   sgl_ctx* c = new (std::nothrow) sgl_ctx();
@@ -337,6 +340,10 @@ int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const
                    int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
                    float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
                    sgl_stream stream);
+int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last,
+                      int B, int H, int W, int interpolate_pos, float* const* hs_slots, float* last_hidden,
+                      float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                      int first_trainable_block, sgl_stream stream);
 
 int sgl_forward(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
                 int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
@@ -351,20 +358,38 @@ int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const
                    int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,
                    float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
                    sgl_stream stream) {
-  if (!ctx || !w || !shadow || !pixels || !hidden_states || !last_hidden) return SGL_ERR_NULL;
+  if (!ctx || !hidden_states) return SGL_ERR_NULL;
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  if (hs_slots < 2 || (saved && hs_slots < ctx->L + 1)) return SGL_ERR_BAD_SHAPE;
+  const size_t hs_stride = (size_t)B * (H / ctx->P) * (W / ctx->P) * ctx->D;
+  float* slots[kMaxLayers + 1];
+  for (int l = 0; l <= ctx->L; ++l) slots[l] = hidden_states + (size_t)(l % hs_slots) * hs_stride;
+  return sgl_forward_slots(ctx, w, shadow, pixels, channels_last, B, H, W, interpolate_pos, slots, last_hidden,
+                           pooled, saved, saved_bytes, ws, ws_bytes, first_trainable_block, stream);
+}
+
+int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last,
+                      int B, int H, int W, int interpolate_pos, float* const* hs_slots, float* last_hidden,
+                      float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                      int first_trainable_block, sgl_stream stream) {
+  if (!ctx || !w || !shadow || !pixels || !hs_slots || !last_hidden) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  for (int l = 0; l <= ctx->L; ++l)
+    if (!hs_slots[l]) return SGL_ERR_NULL;
   const bool train = saved != nullptr;
+  if (train)   // backward reads every hidden state: the slots must be distinct buffers
+    for (int l = 0; l < ctx->L; ++l)
+      for (int k = l + 1; k <= ctx->L; ++k)
+        if (hs_slots[l] == hs_slots[k]) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, train);
   if (train && saved_bytes < lay.saved_total) return SGL_ERR_WORKSPACE;
   // training forward keeps everything in `saved`; the workspace is only touched by inference and backward
   if (!train && (!ws || ws_bytes < lay.ws_total)) return SGL_ERR_WORKSPACE;
-  if (hs_slots < 2 || (train && hs_slots < ctx->L + 1)) return SGL_ERR_BAD_SHAPE;
   if (!(lay.gh == ctx->g0 && lay.gw == ctx->g0) && !interpolate_pos) return SGL_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   const int D = ctx->D, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh, DP = ctx->DP;
   char* act = train ? reinterpret_cast<char*>(saved) : at(ws, lay.ws_act_off);
-  const size_t hs_stride = (size_t)M * D;
-  auto hs = [&](int l) { return hidden_states + (size_t)(l % hs_slots) * hs_stride; };
+  auto hs = [&](int l) { return hs_slots[l]; };
 
   // ---- embeddings
   CK(im2col(pixels, channels_last, act + lay.a_im2col, dt, B, H, W, ctx->P, ctx->Kp, s));
@@ -549,7 +574,18 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
                        const float* hidden_states, const float* d_last_hidden, const float* d_pooled,
                        const float* d_tap_last, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
                        sgl_stream stream) {
-  if (!ctx || !w || !shadow || !g || !hidden_states) return SGL_ERR_NULL;
+  if (!ctx || !hidden_states) return SGL_ERR_NULL;
+  if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  const size_t stride = (size_t)B * (H / ctx->P) * (W / ctx->P) * ctx->D;
+  return sgl_backward_begin_p(ctx, w, shadow, g, B, H, W, hidden_states + (size_t)ctx->L * stride, d_last_hidden, d_pooled,
+                              d_tap_last, saved, saved_bytes, ws, ws_bytes, stream);
+}
+
+int sgl_backward_begin_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                         const float* hs_last, const float* d_last_hidden, const float* d_pooled,
+                         const float* d_tap_last, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                         sgl_stream stream) {
+  if (!ctx || !w || !shadow || !g || !hs_last) return SGL_ERR_NULL;
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, true);
   RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
@@ -560,7 +596,7 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   const char* act = reinterpret_cast<const char*>(saved);
   float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
   void* gbuf = at(ws, lay.w_g);
-  const float* hsL = hidden_states + (size_t)ctx->L * M * D;
+  const float* hsL = hs_last;
   const float* dlast = d_last_hidden;  // gradient w.r.t. post_layernorm output
   float* gsum = reinterpret_cast<float*>(at(ws, lay.w_gsum));
 
@@ -666,7 +702,17 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
 int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
                        int H, int W, const float* hidden_states, const float* d_tap, int need_dx, const void* saved,
                        size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
-  if (!ctx || !w || !shadow || !g || !hidden_states || !g->layers) return SGL_ERR_NULL;
+  if (!ctx || !hidden_states) return SGL_ERR_NULL;
+  if (layer < 0 || layer >= ctx->L || !shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
+  const size_t stride = (size_t)B * (H / ctx->P) * (W / ctx->P) * ctx->D;
+  return sgl_backward_layer_p(ctx, w, shadow, g, layer, B, H, W, hidden_states + (size_t)layer * stride, d_tap, need_dx,
+                              saved, saved_bytes, ws, ws_bytes, stream);
+}
+
+int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
+                         int H, int W, const float* hs_in, const float* d_tap, int need_dx, const void* saved,
+                         size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream) {
+  if (!ctx || !w || !shadow || !g || !hs_in || !g->layers) return SGL_ERR_NULL;
   if (layer < 0 || layer >= ctx->L) return SGL_ERR_BAD_SHAPE;
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, true);
@@ -679,7 +725,7 @@ int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
   const sgl_layer_grads& lg = g->layers[layer];
   const ShadowLayer& sl = ctx->sh_layers[layer];
   const char* lb = reinterpret_cast<const char*>(saved) + lay.layer_base(layer);
-  const float* x_in = hidden_states + (size_t)layer * M * D;
+  const float* x_in = hs_in;
   const float* xmid = reinterpret_cast<const float*>(lb + lay.r_xmid);
   float* dx = reinterpret_cast<float*>(at(ws, lay.w_dx));
   void* gbuf = at(ws, lay.w_g);

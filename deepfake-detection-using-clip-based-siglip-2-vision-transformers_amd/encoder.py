@@ -18,8 +18,10 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import warnings
+import weakref
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -111,164 +113,231 @@ class VisionModelOutput:
 
 
 # ---------------------------------------------------------------------------------------------------------
-# autograd bridge
+# PyTorch custom ops over the C ABI (SURVEY.md §8b "Who calls it"): torch.ops.siglip_hip.encoder_fwd / encoder_bwd,
+# with fake (meta) implementations and a registered autograd formula, so that torch.compile(fullgraph=True) of the
+# SURROUNDING model (cifake_binary_classifier.py:1888, hidf_video_classifier.py:2922) traces straight through the
+# encoder call without a graph break.  The ops are thin: they allocate outputs through PyTorch and make the ctypes calls.
 # ---------------------------------------------------------------------------------------------------------
-class _EncoderFn(torch.autograd.Function):
-    """One autograd node for the whole encoder.  Inputs: pixels + every parameter (fixed order, see
-    ``SiglipVisionModelHIP._flat_params``).  Outputs: pooled, last_hidden_state, then the requested
-    hidden-state taps as separate tensors (so unused taps cost no gradient memory)."""
+_MODULES: "weakref.WeakValueDictionary[int, SiglipVisionModelHIP]" = weakref.WeakValueDictionary()
+_NEXT_HANDLE = [1]
 
-    @staticmethod
-    def forward(ctx, mod, train, interp, want_pooled, tap_ids, pixel_values, *params):
-        L, D = mod.config.num_hidden_layers, mod.config.hidden_size
-        lib = _lib.load()
-        px = pixel_values
-        if px.dim() != 4 or px.shape[1] != 3:
-            raise ValueError(f"pixel_values must be (B,3,H,W), got {tuple(px.shape)}")
-        if px.dtype != torch.float32:
-            px = px.float()
-        channels_last = 0
-        if not px.is_contiguous():
-            if px.is_contiguous(memory_format=torch.channels_last):
-                channels_last = 1
-            else:
-                px = px.contiguous()
-        B, _, H, W = px.shape
-        P = mod.config.patch_size
-        if H < P or W < P:
-            raise ValueError(f"image size ({H},{W}) is smaller than patch_size {P}")
-        gh, gw = H // P, W // P
-        N, M = gh * gw, B * gh * gw
-        if (gh, gw) != (mod.config.native_grid, mod.config.native_grid) and not interp:
-            raise ValueError(f"Input image size ({H}*{W}) doesn't match model native "
-                             f"({mod.config.image_size}*{mod.config.image_size}); pass interpolate_pos_encoding=True")
-        dev = px.device
+
+def _module_of(handle: int) -> "SiglipVisionModelHIP":
+    mod = _MODULES.get(int(handle))
+    if mod is None:
+        raise RuntimeError(f"siglip_hip: encoder handle {handle} is not alive (module was deleted)")
+    return mod
+
+
+def _geometry(mod, pixel_values):
+    if pixel_values.dim() != 4 or pixel_values.shape[1] != 3:
+        raise ValueError(f"pixel_values must be (B,3,H,W), got {tuple(pixel_values.shape)}")
+    B, _, H, W = pixel_values.shape
+    P = mod.config.patch_size
+    if H < P or W < P:
+        raise ValueError(f"image size ({H},{W}) is smaller than patch_size {P}")
+    gh, gw = H // P, W // P
+    return B, H, W, gh * gw, B * gh * gw, (gh, gw)
+
+
+@torch.library.custom_op("siglip_hip::encoder_fwd", mutates_args=())
+def encoder_fwd(pixel_values: torch.Tensor, params: Sequence[torch.Tensor], handle: int, train: bool, interp: bool,
+                want_pooled: bool, tap_ids: Sequence[int], first_trainable: int) -> List[torch.Tensor]:
+    """sgl_forward_slots.  Returns [pooled (B,D) or empty, last_hidden_state (B,N,D), one (B,N,D) tensor per entry of
+    tap_ids (distinct, ascending), saved (uint8 activation arena, empty when not training), hs_rest (the hidden-state
+    slots nobody asked for: [n, B*N, D])].  No output aliases another."""
+    mod = _module_of(handle)
+    cfg = mod.config
+    L, D = cfg.num_hidden_layers, cfg.hidden_size
+    lib = _lib.load()
+    px = pixel_values
+    if px.dtype != torch.float32:
+        px = px.float()
+    channels_last = 0
+    if not px.is_contiguous():
+        if px.is_contiguous(memory_format=torch.channels_last):
+            channels_last = 1
+        else:
+            px = px.contiguous()
+    B, H, W, N, M, grid = _geometry(mod, px)
+    if grid != (cfg.native_grid, cfg.native_grid) and not interp:
+        raise ValueError(f"Input image size ({H}*{W}) doesn't match model native "
+                         f"({cfg.image_size}*{cfg.image_size}); pass interpolate_pos_encoding=True")
+    dev = px.device
+    with torch.cuda.device(dev):
         shadow, weights = mod._prepared(dev)
         sizes = mod._sizes(B, H, W, train)
-        keep_all = train or len(tap_ids) > 0
-        hs_slots = L + 1 if keep_all else 2
-        hs = torch.empty((hs_slots, M, D), dtype=torch.float32, device=dev)
-        last = torch.empty((M, D), dtype=torch.float32, device=dev)
-        pooled = torch.empty((B, D), dtype=torch.float32, device=dev) if want_pooled else None
-        saved = torch.empty(sizes[1], dtype=torch.uint8, device=dev) if train else None
-        ws = None if train else torch.empty(sizes[2], dtype=torch.uint8, device=dev)
-        # first block that can receive a gradient (frozen prefix, Siglip2sidafrozen.py:757-768); 0 when the embeddings train
-        first = 0
-        if train:
-            trainable = {grp for (grp, _), p in zip(mod._flat_names, params) if p.requires_grad}
-            if "emb" not in trainable:
-                first = min([int(g_[5:]) for g_ in trainable if g_.startswith("layer")] or [L])
-        st = lib.sgl_forward_ex(mod._ctx, C.byref(weights), shadow.data_ptr(), px.data_ptr(), channels_last, B, H, W,
-                                1 if interp else 0, hs.data_ptr(), hs_slots, last.data_ptr(), _lib.ptr(pooled),
-                                _lib.ptr(saved), sizes[1] if train else 0, _lib.ptr(ws), 0 if train else sizes[2],
-                                first, _lib.current_stream_handle())
-        _lib.check(st, "sgl_forward_ex", mod._ctx)
-        if train:
-            ctx.mod, ctx.saved, ctx.hs, ctx.geom, ctx.interp = mod, saved, hs, (B, H, W, N, M), interp
-            ctx.tap_ids, ctx.want_pooled, ctx.weights, ctx.shadow = tap_ids, want_pooled, weights, shadow
-        outs = [pooled if want_pooled else last.new_zeros(()), last.view(B, N, D)]
-        outs += [hs[i].view(B, N, D) for i in tap_ids]
-        dead = [] if want_pooled else [outs[0]]
-        if train:
-            # hidden_states[i] only feeds gradient to the embeddings and to blocks < i: with those frozen
-            # (Siglip2sidafrozen.py:757-768) the tap's gradient would be computed by the consumer (the SID decoder's
-            # tap projections) and then dropped here, so tell autograd not to ask for it
-            if "emb" not in trainable:
-                dead += [t for i, t in zip(tap_ids, outs[2:]) if i <= first]
-        if dead:
-            ctx.mark_non_differentiable(*dead)
-        return tuple(outs)
+        taps = [torch.empty((B, N, D), dtype=torch.float32, device=dev) for _ in tap_ids]
+        tapset = {int(t): i for i, t in enumerate(tap_ids)}
+        n_rest = (L + 1 - len(tapset)) if train else min(2, L + 1 - len(tapset))
+        hs_rest = torch.empty((n_rest, M, D), dtype=torch.float32, device=dev)
+        slots = (_lib._fp * (L + 1))()
+        k = 0
+        for l in range(L + 1):
+            if l in tapset:
+                slots[l] = taps[tapset[l]].data_ptr()
+            elif train:
+                slots[l] = hs_rest[k].data_ptr()
+                k += 1
+            else:
+                slots[l] = hs_rest[l & 1].data_ptr()     # inference: ping-pong (neighbours differ in parity)
+        last = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, D) if want_pooled else (0,), dtype=torch.float32, device=dev)
+        saved = torch.empty(sizes[1] if train else 0, dtype=torch.uint8, device=dev)
+        ws = None if train else mod._workspace(sizes[2], dev)
+        st = lib.sgl_forward_slots(mod._ctx, C.byref(weights), shadow.data_ptr(), px.data_ptr(), channels_last, B, H, W,
+                                   1 if interp else 0, slots, last.data_ptr(),
+                                   pooled.data_ptr() if want_pooled else None, saved.data_ptr() if train else None,
+                                   sizes[1] if train else 0, _lib.ptr(ws), 0 if train else sizes[2],
+                                   int(first_trainable), _lib.current_stream_handle())
+        _lib.check(st, "sgl_forward_slots", mod._ctx)
+    if train:
+        mod._note_forward(saved)
+    return [pooled, last, *taps, saved, hs_rest]
 
-    @staticmethod
-    def backward(ctx, d_pooled, d_last, *d_taps):
-        mod = ctx.mod
-        lib = _lib.load()
-        cfg = mod.config
-        L, D = cfg.num_hidden_layers, cfg.hidden_size
-        B, H, W, N, M = ctx.geom
-        dev = ctx.hs.device
-        needs = ctx.needs_input_grad[6:]
-        names = mod._flat_names
-        params = mod._flat_params()
 
-        def prep(g):
-            if g is None:
-                return None
-            g = g.float() if g.dtype != torch.float32 else g
-            return g.contiguous()
+@encoder_fwd.register_fake
+def _(pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable):
+    mod = _module_of(handle)
+    cfg = mod.config
+    L, D = cfg.num_hidden_layers, cfg.hidden_size
+    B, H, W, N, M, _ = _geometry(mod, pixel_values)
+    if not all(isinstance(v, int) for v in (B, H, W)):
+        raise RuntimeError("siglip_hip::encoder_fwd needs static image shapes under torch.compile (dynamic=False)")
+    new = pixel_values.new_empty
+    n_rest = (L + 1 - len(tap_ids)) if train else min(2, L + 1 - len(tap_ids))
+    saved_bytes = mod._sizes(B, H, W, True)[1] if train else 0
+    return [new((B, D) if want_pooled else (0,), dtype=torch.float32), new((B, N, D), dtype=torch.float32),
+            *[new((B, N, D), dtype=torch.float32) for _ in tap_ids], new((saved_bytes,), dtype=torch.uint8),
+            new((n_rest, M, D), dtype=torch.float32)]
 
-        d_pooled = prep(d_pooled) if ctx.want_pooled else None
-        d_last = prep(d_last)
-        tap_grads = [None] * (L + 1)
-        for i, g in zip(ctx.tap_ids, d_taps):
-            if g is not None:
-                g = prep(g)
-                tap_grads[i] = g if tap_grads[i] is None else tap_grads[i] + g
 
-        # gradient buffers: one flat fp32 bucket per group (embeddings, each block, post-LN + head)
-        grads_out = [None] * len(params)
-        groups: dict[str, list[int]] = {}
-        for idx, (grp, field) in enumerate(names):
-            if needs[idx]:
-                groups.setdefault(grp, []).append(idx)
-        buckets: dict[str, torch.Tensor] = {}
-        # q/k/v weight (and bias) gradients back to back: the C side then runs them as one dW GEMM / one column sum
-        rank = {"q_w": 0, "k_w": 1, "v_w": 2, "q_b": 3, "k_b": 4, "v_b": 5}
-        for grp, idxs in groups.items():
-            idxs.sort(key=lambda i: (rank.get(names[i][1], 6), i))
-            total = sum((params[i].numel() + 3) // 4 * 4 for i in idxs)   # every tensor 16-byte aligned
-            flat = torch.zeros(total, dtype=torch.float32, device=dev)
-            off = 0
-            for i in idxs:
-                n = params[i].numel()
-                grads_out[i] = flat[off:off + n].view(params[i].shape)
-                off += (n + 3) // 4 * 4
-            buckets[grp] = flat
+@torch.library.custom_op("siglip_hip::encoder_bwd", mutates_args=())
+def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Tensor], saved: torch.Tensor,
+                hs_rest: torch.Tensor, params: Sequence[torch.Tensor], handle: int, image_hw: Sequence[int],
+                interp: bool, want_pooled: bool, tap_ids: Sequence[int], needs: Sequence[bool]) -> List[torch.Tensor]:
+    """sgl_backward_begin_p -> sgl_backward_layer_p (L-1 ... first trainable block) -> sgl_backward_embed.
+    grads = [d pooled, d last_hidden_state, d tap...] (None = no gradient).  Returns one tensor per parameter (views of
+    one flat fp32 bucket per block / group — the DDP all-reduce unit; an empty tensor where needs[i] is False)."""
+    mod = _module_of(handle)
+    lib = _lib.load()
+    cfg = mod.config
+    L, D = cfg.num_hidden_layers, cfg.hidden_size
+    H, W = int(image_hw[0]), int(image_hw[1])
+    dev = saved.device
+    B = int(taps[0].shape[0]) if len(taps) else int(hs_rest.shape[1] // ((H // cfg.patch_size) * (W // cfg.patch_size)))
+    N = (H // cfg.patch_size) * (W // cfg.patch_size)
+    M = B * N
+    mod._check_backward(saved)
+    names = mod._flat_names
+    params = mod._flat_params()
 
+    def prep(g):
+        if g is None:
+            return None
+        g = g.float() if g.dtype != torch.float32 else g
+        return g.contiguous()
+
+    d_pooled = prep(grads[0]) if want_pooled else None
+    d_last = prep(grads[1])
+    tap_grads = [None] * (L + 1)
+    hs_ptr = [None] * (L + 1)
+    k = 0
+    tapset = {int(t): i for i, t in enumerate(tap_ids)}
+    for l in range(L + 1):
+        if l in tapset:
+            hs_ptr[l] = taps[tapset[l]].data_ptr()
+            tap_grads[l] = prep(grads[2 + tapset[l]])
+        else:
+            hs_ptr[l] = hs_rest[k].data_ptr()
+            k += 1
+
+    with torch.cuda.device(dev):
+        grads_out, buckets, groups = mod._grad_buckets(needs, dev)
+        if d_pooled is None and "head" in buckets:
+            buckets["head"].zero_()      # the C side skips the pooling head (and post-LN when d_last is None too)
         gl = (_lib.SglLayerPtrs * max(L, 1))()
         g = _lib.SglGrads()
         g.layers = C.cast(gl, C.POINTER(_lib.SglLayerPtrs))
         g.accumulate = 0
         for idx, (grp, field) in enumerate(names):
-            p = None if grads_out[idx] is None else grads_out[idx].data_ptr()
+            ptr = None if grads_out[idx] is None else grads_out[idx].data_ptr()
             if grp.startswith("layer"):
-                setattr(gl[int(grp[5:])], field, p)
+                setattr(gl[int(grp[5:])], field, ptr)
             else:
-                setattr(g, field, p)
+                setattr(g, field, ptr)
 
         train_emb = "emb" in groups
-        layer_ids = sorted(int(k[5:]) for k in groups if k.startswith("layer"))
+        layer_ids = sorted(int(k_[5:]) for k_ in groups if k_.startswith("layer"))
         first = layer_ids[0] if layer_ids else L
         stop = 0 if train_emb else first
         sizes = mod._sizes(B, H, W, True)
-        ws = torch.empty(sizes[2], dtype=torch.uint8, device=dev)
+        ws = mod._workspace(sizes[2], dev)
         stream = _lib.current_stream_handle()
-        wts, shadow = ctx.weights, ctx.shadow
+        shadow, wts = mod._shadow, mod._weights_struct
         reducer = mod._grad_reducer
-        st = lib.sgl_backward_begin(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), B, H, W, ctx.hs.data_ptr(),
-                                    _lib.ptr(d_last), _lib.ptr(d_pooled), _lib.ptr(tap_grads[L]),
-                                    ctx.saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
-        _lib.check(st, "sgl_backward_begin", mod._ctx)
+        st = lib.sgl_backward_begin_p(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), B, H, W, hs_ptr[L],
+                                      _lib.ptr(d_last), _lib.ptr(d_pooled), _lib.ptr(tap_grads[L]),
+                                      saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
+        _lib.check(st, "sgl_backward_begin_p", mod._ctx)
         if reducer is not None and "head" in buckets:
             reducer.reduce_bucket(buckets["head"])
         for l in range(L - 1, stop - 1, -1):
             need_dx = 1 if (l > stop or train_emb) else 0
-            st = lib.sgl_backward_layer(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), l, B, H, W,
-                                        ctx.hs.data_ptr(), _lib.ptr(tap_grads[l]), need_dx, ctx.saved.data_ptr(),
-                                        sizes[1], ws.data_ptr(), sizes[2], stream)
-            _lib.check(st, f"sgl_backward_layer[{l}]", mod._ctx)
+            st = lib.sgl_backward_layer_p(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), l, B, H, W, hs_ptr[l],
+                                          _lib.ptr(tap_grads[l]), need_dx, saved.data_ptr(), sizes[1], ws.data_ptr(),
+                                          sizes[2], stream)
+            _lib.check(st, f"sgl_backward_layer_p[{l}]", mod._ctx)
             if reducer is not None and f"layer{l}" in buckets:
                 reducer.reduce_bucket(buckets[f"layer{l}"])
         if train_emb:
-            st = lib.sgl_backward_embed(mod._ctx, C.byref(wts), C.byref(g), B, H, W, 1 if ctx.interp else 0,
-                                        ctx.saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
+            st = lib.sgl_backward_embed(mod._ctx, C.byref(wts), C.byref(g), B, H, W, 1 if interp else 0,
+                                        saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
             _lib.check(st, "sgl_backward_embed", mod._ctx)
             if reducer is not None:
                 reducer.reduce_bucket(buckets["emb"])
         if reducer is not None:
             reducer.finish()
-        ctx.saved = ctx.hs = None
-        return (None, None, None, None, None, None, *grads_out)
+    empty = saved.new_empty((0,), dtype=torch.float32)
+    return [empty if t is None else t for t in grads_out]
+
+
+@encoder_bwd.register_fake
+def _(grads, taps, saved, hs_rest, params, handle, image_hw, interp, want_pooled, tap_ids, needs):
+    return [torch.empty_like(p) if n else p.new_empty((0,)) for p, n in zip(params, needs)]
+
+
+def _encoder_setup_context(ctx, inputs, output):
+    pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable = inputs
+    ctx.set_materialize_grads(False)
+    ctx.handle, ctx.interp, ctx.want_pooled, ctx.tap_ids = handle, interp, want_pooled, list(tap_ids)
+    ctx.image_hw = [int(pixel_values.shape[2]), int(pixel_values.shape[3])]
+    ctx.ntaps, ctx.nparams, ctx.train = len(tap_ids), len(params), train
+    if train:
+        # saving the taps (outputs) makes autograd's version counter catch a consumer's in-place edit of a hidden state
+        ctx.save_for_backward(*output[2:], *params)
+        # hidden_states[i] only feeds gradient to the embeddings and to blocks < i: with those frozen
+        # (Siglip2sidafrozen.py:757-768) the tap's gradient would be computed by the consumer (the SID decoder's tap
+        # projections) and then dropped here, so tell autograd not to ask for it
+        dead = [t for i, t in zip(tap_ids, output[2:2 + len(tap_ids)]) if first_trainable > 0 and i <= first_trainable]
+        dead += [output[-2], output[-1]] + ([] if want_pooled else [output[0]])
+        ctx.mark_non_differentiable(*dead)
+
+
+def _encoder_backward(ctx, grads):
+    if not ctx.train:
+        raise RuntimeError("siglip_hip::encoder_fwd was run with train=False: nothing was saved for backward")
+    saved_t = ctx.saved_tensors
+    nt = ctx.ntaps
+    taps, saved, hs_rest, params = list(saved_t[:nt]), saved_t[nt], saved_t[nt + 1], list(saved_t[nt + 2:])
+    needs = [bool(n) for n in ctx.needs_input_grad[1]] if isinstance(ctx.needs_input_grad[1], (list, tuple)) \
+        else [p.requires_grad for p in params]
+    out = torch.ops.siglip_hip.encoder_bwd(list(grads[:2 + nt]), taps, saved, hs_rest, params, ctx.handle, ctx.image_hw,
+                                           ctx.interp, ctx.want_pooled, ctx.tap_ids, needs)
+    return None, [o if n else None for o, n in zip(out, needs)], None, None, None, None, None, None
+
+
+encoder_fwd.register_autograd(_encoder_backward, setup_context=_encoder_setup_context)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -287,6 +356,15 @@ def _hf_load_pre_hook(state_dict, prefix, local_metadata, strict, missing_keys, 
         state_dict[prefix + k[len(pv):]] = state_dict.pop(k)
 
 
+def vision_tower_only(state_dict: dict) -> dict:
+    """Keep the vision tower of a full SiglipModel checkpoint: keys under ``vision_model.`` when that level exists (the
+    published google/siglip* files also carry ``text_model.*``, ``logit_scale``, ``logit_bias``), everything otherwise."""
+    if any(k.startswith("vision_model.") for k in state_dict):
+        return {k: v for k, v in state_dict.items() if k.startswith("vision_model.")}
+    return {k: v for k, v in state_dict.items()
+            if not (k.startswith("text_model.") or k in ("logit_scale", "logit_bias"))}
+
+
 class SiglipVisionModelHIP(nn.Module):
     """Drop-in for ``transformers.SiglipVisionModel`` on the reference's path (see module docstring)."""
 
@@ -303,16 +381,10 @@ class SiglipVisionModelHIP(nn.Module):
         self.use_head = bool(cfg.vision_use_head)
         if self.use_head:
             self.head = _HeadParams(cfg)
-        self._ctx = None
-        self._shadow = None
-        self._shadow_key = None
-        self._weights_struct = None
-        self._weights_keep = None
-        self._weights_key = None
-        self._size_cache: dict = {}
         self._grad_reducer = None
         self._gradient_checkpointing = False
         self._flat_names = self._build_names()
+        self._reset_runtime_state()
         # checkpoints keep transformers' key names (``vision_model.encoder.layers.N…``, Siglip2sidafrozen.py:1639)
         self._register_state_dict_hook(_hf_state_dict_hook)
         self._register_load_state_dict_pre_hook(_hf_load_pre_hook)
@@ -325,10 +397,13 @@ class SiglipVisionModelHIP(nn.Module):
         return self
 
     @classmethod
-    def from_pretrained(cls, name_or_path: str, compute_dtype: str = "bf16", seed: int = 0):
-        """Local directory (``config.json`` + ``model.safetensors``), a ``.safetensors`` file next to a
-        ``config.json``, or a known config name.  There is no network: a bare name gives the closed-form
-        seeded initialisation of that architecture (``weights.seeded_state_dict``)."""
+    def from_pretrained(cls, name_or_path: str, compute_dtype: str = "bf16", seed: int = 0,
+                        allow_random_init: bool = False):
+        """Local directory (``config.json`` + ``model.safetensors``) or a known config name.  A published
+        google/siglip(2) checkpoint is the FULL SiglipModel (``vision_model.*``, ``text_model.*``, ``logit_scale``,
+        ``logit_bias``): like ``SiglipVisionModel.from_pretrained`` (Siglip2sidafrozen.py:753) only the vision tower is
+        kept.  There is no network: a bare name has no weights to load, which is an error unless
+        ``allow_random_init=True`` asks for the closed-form seeded initialisation (``weights.seeded_state_dict``)."""
         if os.path.isdir(name_or_path):
             with open(os.path.join(name_or_path, "config.json")) as f:
                 raw = json.load(f)
@@ -337,9 +412,17 @@ class SiglipVisionModelHIP(nn.Module):
             cfg = SiglipVisionConfig(**{k: v for k, v in raw.items() if k in fields})
             model = cls(cfg, compute_dtype)
             from safetensors.torch import load_file
-            model.load_state_dict(load_file(os.path.join(name_or_path, "model.safetensors")))
+            model.load_state_dict(vision_tower_only(load_file(os.path.join(name_or_path, "model.safetensors"))))
             return model
         if name_or_path in NAMED_CONFIGS:
+            if not allow_random_init:
+                raise OSError(
+                    f"'{name_or_path}' names an architecture, not a local checkpoint directory, and there is no network "
+                    "to fetch pretrained weights from.  Pass a directory holding config.json + model.safetensors, or "
+                    "allow_random_init=True to get SEEDED RANDOM weights of that architecture (benchmarks / tests).")
+            warnings.warn(f"SiglipVisionModelHIP.from_pretrained('{name_or_path}'): no checkpoint — using seeded RANDOM "
+                          "weights (allow_random_init=True); outputs are not those of the pretrained model",
+                          stacklevel=2)
             model = cls(get_config(name_or_path), compute_dtype)
             model.load_state_dict(seeded_state_dict(model.config, seed))
             return model
@@ -347,8 +430,12 @@ class SiglipVisionModelHIP(nn.Module):
                       f"(no network access); known: {sorted(NAMED_CONFIGS)}")
 
     def gradient_checkpointing_enable(self, **_):
-        """Accepted for interface parity (``Siglip2sidafrozen.py:1195-1196``).  Activations for a 64-image
-        so400m batch (≈52 GB) fit the 288 GB of HBM3E, so nothing is recomputed."""
+        """Accepted for interface parity (``Siglip2sidafrozen.py:1195-1196``) but does nothing, and says so once:
+        activations of a 128-image so400m batch (87 GB) fit the 288 GB of HBM3E, so nothing is recomputed."""
+        if not self._gradient_checkpointing:
+            warnings.warn("SiglipVisionModelHIP.gradient_checkpointing_enable(): no-op — the HIP encoder keeps all "
+                          "activations (0.68 GB per so400m@384 image; 288 GB HBM3E) and never recomputes",
+                          stacklevel=2)
         self._gradient_checkpointing = True
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -359,13 +446,15 @@ class SiglipVisionModelHIP(nn.Module):
             state_dict = weights_io.encoder_state_from_checkpoint(state_dict, self.config)
         return super().load_state_dict(dict(state_dict), strict=strict, **kw)
 
-    @torch.compiler.disable   # the reference torch.compile()s its models (cifake…:1888, hidf…:2922): Dynamo must not
-    # trace into the ctypes calls; the encoder is one opaque eager region and the graph breaks cleanly around it
     def forward(self, pixel_values, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
                 hidden_state_ids=None, **_):
+        """Traceable by Dynamo: everything device-side happens inside ``torch.ops.siglip_hip.encoder_fwd``."""
         if pixel_values.device.type != "cuda":
             raise RuntimeError("SiglipVisionModelHIP runs only on an AMD GPU through libsiglip_hip.so "
                                "(no CPU fallback); move the model and pixel_values to 'cuda'")
+        if pixel_values.requires_grad:
+            raise RuntimeError("SiglipVisionModelHIP does not differentiate with respect to pixel_values (the reference "
+                               "never asks for it); detach the input")
         L = self.config.num_hidden_layers
         if hidden_state_ids is not None:
             tap_ids = tuple(int(i) % (L + 1) for i in hidden_state_ids)
@@ -373,14 +462,21 @@ class SiglipVisionModelHIP(nn.Module):
             tap_ids = tuple(range(L + 1))
         else:
             tap_ids = ()
+        uniq = sorted(set(tap_ids))
         params = self._flat_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        outs = _EncoderFn.apply(self, train, bool(interpolate_pos_encoding), self.use_head, tap_ids, pixel_values,
-                                *params)
+        # first block that can receive a gradient (frozen prefix, Siglip2sidafrozen.py:757-768); 0 when the embeddings train
+        first = 0
+        if train and not any(p.requires_grad for p in params[:3]):
+            first = L
+            for (grp, _), p in zip(self._flat_names, params):
+                if p.requires_grad and grp.startswith("layer"):
+                    first = int(grp[5:])
+                    break
+        outs = torch.ops.siglip_hip.encoder_fwd(pixel_values, params, self._handle, train,
+                                                bool(interpolate_pos_encoding), self.use_head, uniq, first)
         pooled = outs[0] if self.use_head else None
-        hs = tuple(outs[2:]) if tap_ids else None
-        if hs is not None and hidden_state_ids is None and output_hidden_states:
-            pass
+        hs = tuple(outs[2 + uniq.index(i)] for i in tap_ids) if tap_ids else None
         return VisionModelOutput(last_hidden_state=outs[1], pooler_output=pooled, hidden_states=hs)
 
     # ---- plumbing ----------------------------------------------------------------------------------------
@@ -409,7 +505,95 @@ class SiglipVisionModelHIP(nn.Module):
                    h.mlp.fc2.weight, h.mlp.fc2.bias]
         return ps
 
+    def _reset_runtime_state(self):
+        """Everything that belongs to THIS Python object (not to its parameters): C context, op handle, caches."""
+        self._ctx = None
+        self._shadow = None
+        self._shadow_key = None
+        self._shadow_serial = 0
+        self._weights_struct = None
+        self._weights_keep = None
+        self._weights_key = None
+        self._size_cache = {}
+        self._ws_cache = None
+        self._bucket_cache = {}
+        self._pending_fwd = {}
+        self._owner = id(self)
+        self._handle = _NEXT_HANDLE[0]
+        _NEXT_HANDLE[0] += 1
+        _MODULES[self._handle] = self
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy (EMA / SWA wrappers): a fresh module with copied parameters and its own C context."""
+        new = type(self)(self.config, self.compute_dtype)
+        new.load_state_dict(self.state_dict())
+        new.to(next(self.parameters()).device)
+        for a, b in zip(new.parameters(), self.parameters()):
+            a.requires_grad = b.requires_grad
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
+
+    def _workspace(self, nbytes, dev):
+        """Scratch reused across calls (stream-ordered; the C side only needs it intact within one forward / backward)."""
+        ws = self._ws_cache
+        if ws is None or ws.device != dev or ws.numel() < nbytes:
+            self._ws_cache = ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws
+
+    def _note_forward(self, saved):
+        """Remember which weight-shadow generation a training forward used (checked by its backward)."""
+        if len(self._pending_fwd) > 64:
+            self._pending_fwd.clear()
+        self._pending_fwd[saved.data_ptr()] = self._shadow_serial
+
+    def _check_backward(self, saved):
+        serial = self._pending_fwd.get(saved.data_ptr())
+        if serial is not None and serial != self._shadow_serial:
+            raise RuntimeError(
+                "SiglipVisionModelHIP: parameters changed between this forward and its backward (optimizer step, EMA "
+                "swap or load_state_dict in between re-cast the bf16 weight shadows); run backward before touching them")
+
+    def _grad_buckets(self, needs, dev):
+        """One flat fp32 bucket per group (embeddings, each block, post-LN + head) with the per-parameter gradient views
+        inside; the C side overwrites every element, so the buckets are reused from step to step (no memset, stable
+        pointers for FusedAdamW's device table) unless a parameter's .grad still aliases them (gradient accumulation,
+        zero_grad(set_to_none=False)), in which case this backward gets fresh memory."""
+        names = self._flat_names
+        params = self._flat_params()
+        groups: dict[str, list[int]] = {}
+        for idx, (grp, _) in enumerate(names):
+            if needs[idx]:
+                groups.setdefault(grp, []).append(idx)
+        # q/k/v weight (and bias) gradients back to back: the C side then runs them as one dW GEMM / one column sum
+        rank = {"q_w": 0, "k_w": 1, "v_w": 2, "q_b": 3, "k_b": 4, "v_b": 5}
+        grads_out = [None] * len(params)
+        buckets: dict[str, torch.Tensor] = {}
+        for grp, idxs in groups.items():
+            idxs.sort(key=lambda i: (rank.get(names[i][1], 6), i))
+            total = sum((params[i].numel() + 3) // 4 * 4 for i in idxs)   # every tensor 16-byte aligned
+            key = (grp, tuple(idxs))
+            flat = self._bucket_cache.get(key)
+            if flat is not None and (flat.device != dev or flat.numel() != total):
+                flat = None
+            if flat is not None:
+                base, end = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+                if any(params[i].grad is not None and base <= params[i].grad.data_ptr() < end for i in idxs):
+                    flat = None
+            if flat is None:
+                flat = torch.empty(total, dtype=torch.float32, device=dev)
+                self._bucket_cache[key] = flat
+            off = 0
+            for i in idxs:
+                n = params[i].numel()
+                grads_out[i] = flat[off:off + n].view(params[i].shape)
+                off += (n + 3) // 4 * 4
+            buckets[grp] = flat
+        return grads_out, buckets, groups
+
     def _ensure_ctx(self):
+        if self._owner != id(self):      # object was copied field by field (copy.copy): do not share the original's state
+            self._reset_runtime_state()
         if self._ctx is None:
             lib = _lib.load()
             cfg = self.config
@@ -490,6 +674,7 @@ class SiglipVisionModelHIP(nn.Module):
                                                self._shadow.numel(), dirty, glob, _lib.current_stream_handle())
             _lib.check(st, "sgl_prepare_weights_dirty", self._ctx)
             self._shadow_key = keys
+            self._shadow_serial += 1
         return self._shadow, self._weights_struct
 
     def _apply(self, fn, *a, **kw):
@@ -497,6 +682,8 @@ class SiglipVisionModelHIP(nn.Module):
         self._shadow = None
         self._shadow_key = None
         self._weights_struct = None
+        self._ws_cache = None
+        self._bucket_cache = {}
         return out
 
     def __del__(self):
@@ -604,8 +791,12 @@ def create_model_and_transforms(model_name: str, pretrained: Optional[str] = Non
     model = OpenClipStyleEncoder(cfg, compute_dtype)
     if pretrained and os.path.isdir(pretrained):
         from safetensors.torch import load_file
-        model.visual.load_state_dict(load_file(os.path.join(pretrained, "model.safetensors")))
+        model.visual.load_state_dict(vision_tower_only(load_file(os.path.join(pretrained, "model.safetensors"))))
     else:
+        if pretrained:   # 'webli' & co.: a hub tag, not a local directory
+            warnings.warn(f"create_model_and_transforms('{model_name}', pretrained='{pretrained}'): no network and no "
+                          "local checkpoint directory — the encoder gets seeded RANDOM weights, not the pretrained "
+                          "ones; pass pretrained=<dir with model.safetensors> for real weights", stacklevel=2)
         model.visual.load_state_dict(seeded_state_dict(cfg, seed))
     model = model.to(device)
     pre = _preprocess_factory(cfg.image_size)

@@ -37,6 +37,33 @@ class _TapProj(nn.Module):
         return _linear_tokens(x, self.proj.weight, self.proj.bias)
 
 
+_W_CACHE: dict = {}       # (data_ptr, shape) -> (version, bf16 W, bf16 Wᵀ or None)
+_SCRATCH: dict = {}       # device -> 64 MiB split-K scratch, reused by every call (stream-ordered)
+
+
+def _cached_bf16(weight: torch.Tensor, want_t: bool):
+    """bf16 copy (and, on demand, transposed copy) of a weight, re-made only when the parameter changed (optimizer steps
+    bump ``_version``): the decoder has ~40 Linear layers and used to re-cast + re-transpose each one on every call."""
+    key = (weight.data_ptr(), tuple(weight.shape))
+    hit = _W_CACHE.get(key)
+    if hit is None or hit[0] != weight._version:
+        if len(_W_CACHE) > 256:
+            _W_CACHE.clear()
+        hit = (weight._version, weight.detach().to(torch.bfloat16).contiguous(), None)
+        _W_CACHE[key] = hit
+    if want_t and hit[2] is None:
+        hit = (hit[0], hit[1], hit[1].t().contiguous())
+        _W_CACHE[key] = hit
+    return hit[1], hit[2]
+
+
+def _split_scratch(dev):
+    buf = _SCRATCH.get(dev)
+    if buf is None:
+        buf = _SCRATCH[dev] = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    return buf
+
+
 class _HipLinearFn(torch.autograd.Function):
     """y = x Wᵀ + b on bf16 token-major activations through the encoder's own MFMA GEMM kernels (sgl_op_gemm_nt /
     sgl_op_gemm_tn): the decoder's tall-skinny shapes (46656 x 512 x 1152, 46656 x 512 x 512 ...) are where the
@@ -50,13 +77,14 @@ class _HipLinearFn(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         xb = x.to(torch.bfloat16).contiguous()
-        wb = weight.detach().to(torch.bfloat16).contiguous()
+        wb, _ = _cached_bf16(weight, False)
         bf = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty(M, N, device=x.device, dtype=torch.bfloat16)
         _lib.check(lib.sgl_op_gemm_nt(_lib.SGL_DTYPE_BF16, xb.data_ptr(), K, wb.data_ptr(), K, M, N, K, _lib.EPI_STORE,
                                       y.data_ptr(), N, None, 0, _lib.ptr(bf), None, 0, None, 0, None, 1, 1, 1, 8, 8, 1,
                                       _lib.current_stream_handle()), "sgl_op_gemm_nt")
         ctx.save_for_backward(xb, wb)
+        ctx.weight = weight
         ctx.has_bias = bias is not None
         ctx.wdtype = weight.dtype
         ctx.xdtype = x.dtype
@@ -73,7 +101,11 @@ class _HipLinearFn(torch.autograd.Function):
         stream = _lib.current_stream_handle()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:   # dX[M,K] = dY[M,N] · W[N,K]: NT form with the K x N transpose of W as "B"
-            wt = wb.t().contiguous()
+            hit = _W_CACHE.get((ctx.weight.data_ptr(), tuple(ctx.weight.shape)))
+            if hit is not None and hit[1] is wb:      # still the weight this forward used
+                wt = _cached_bf16(ctx.weight, True)[1]
+            else:
+                wt = wb.t().contiguous()
             dx = torch.empty(M, K, device=xb.device, dtype=torch.bfloat16)
             _lib.check(lib.sgl_op_gemm_nt(_lib.SGL_DTYPE_BF16, dyb.data_ptr(), N, wt.data_ptr(), N, M, K, N,
                                           _lib.EPI_STORE, dx.data_ptr(), K, None, 0, None, None, 0, None, 0, None, 1, 1,
@@ -81,7 +113,7 @@ class _HipLinearFn(torch.autograd.Function):
             dx = dx.to(ctx.xdtype)
         if ctx.needs_input_grad[1]:   # dW[N,K] = dYᵀ · X
             dw = torch.empty(N, K, device=xb.device, dtype=torch.float32)
-            scratch = torch.empty(64 << 20, device=xb.device, dtype=torch.uint8)   # split-K slabs: deterministic sum
+            scratch = _split_scratch(xb.device)   # split-K slabs: deterministic sum
             _lib.check(lib.sgl_op_gemm_tn_ws(_lib.SGL_DTYPE_BF16, dyb.data_ptr(), N, xb.data_ptr(), K, M, N, K, 0,
                                              dw.data_ptr(), K, 0, scratch.data_ptr(), scratch.numel(), stream),
                        "sgl_op_gemm_tn_ws(dW)")

@@ -97,6 +97,12 @@ def load():
                                  _fp, sz, _fp])
     _sig(lib, "sgl_forward_ex", i, [C.c_void_p, C.POINTER(SglWeights), _fp, _fp, i, i, i, i, i, _fp, i, _fp, _fp, _fp, sz,
                                     _fp, sz, i, _fp])
+    _sig(lib, "sgl_forward_slots", i, [C.c_void_p, C.POINTER(SglWeights), _fp, _fp, i, i, i, i, i, C.POINTER(_fp), _fp, _fp,
+                                       _fp, sz, _fp, sz, i, _fp])
+    _sig(lib, "sgl_backward_begin_p", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, _fp, _fp,
+                                          _fp, _fp, _fp, sz, _fp, sz, _fp])
+    _sig(lib, "sgl_backward_layer_p", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, i, _fp,
+                                          _fp, i, _fp, sz, _fp, sz, _fp])
     _sig(lib, "sgl_backward_begin", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, _fp, _fp,
                                         _fp, _fp, _fp, sz, _fp, sz, _fp])
     _sig(lib, "sgl_backward_layer", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglGrads), i, i, i, i, _fp,

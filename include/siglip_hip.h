@@ -134,6 +134,16 @@ int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const
                    float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, int first_trainable_block,
                    sgl_stream stream);
 
+/* sgl_forward_ex with one pointer per hidden-state slot (HOST array of L+1 device pointers, each [B*N][D] fp32) instead
+ * of one [slots][B*N][D] block: the PyTorch custom op (torch.ops.siglip_hip.encoder_fwd) hands the requested taps out as
+ * tensors of their own and keeps the other slots in a private buffer, so no output aliases another.  Inference callers
+ * may point several entries at the same buffer (ping-pong) as long as slots l and l+1 differ; with saved != NULL all
+ * L+1 pointers must be distinct. */
+int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last,
+                      int B, int H, int W, int interpolate_pos, float* const* hs_slots, float* last_hidden,
+                      float* pooled, void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                      int first_trainable_block, sgl_stream stream);
+
 /* ---- backward (stepwise so that a data-parallel caller can all-reduce each block's gradients while the
  *      next block's backward runs; sgl_backward is the plain loop over the three steps) ------------------ */
 /* d_last_hidden [B*N][D], d_pooled [B][D], d_tap_last [B*N][D] (gradient w.r.t. hidden_states[L]); any may be
@@ -148,6 +158,15 @@ int sgl_backward_begin(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, c
 int sgl_backward_layer(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
                        int H, int W, const float* hidden_states, const float* d_tap, int need_dx, const void* saved,
                        size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
+/* The same two steps taking just the hidden state they read (hidden_states[L] / hidden_states[layer]) instead of the
+ * base of a contiguous [L+1][B*N][D] block: for callers that keep the slots in separate buffers (sgl_forward_slots). */
+int sgl_backward_begin_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int B, int H, int W,
+                         const float* hs_last, const float* d_last_hidden, const float* d_pooled,
+                         const float* d_tap_last, const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes,
+                         sgl_stream stream);
+int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const sgl_grads* g, int layer, int B,
+                         int H, int W, const float* hs_in, const float* d_tap, int need_dx, const void* saved,
+                         size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);
 /* Patch-embedding / position-table gradients from the workspace gradient (d hidden_states[0]). */
 int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, int B, int H, int W, int interpolate_pos,
                        const void* saved, size_t saved_bytes, void* ws, size_t ws_bytes, sgl_stream stream);

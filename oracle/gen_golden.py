@@ -47,6 +47,8 @@ CASES = [
     dict(name="hostile_98_interp", config="hostile", seed=6, batch=3, res=98, interp=True, taps=(0, 2)),
     dict(name="so400m1_384", config="so400m-1layer", seed=7, batch=1, res=384, interp=True, taps=(1,)),
     dict(name="so400m1_224_interp", config="so400m-1layer", seed=8, batch=2, res=224, interp=True, taps=(0,)),
+    # BASELINE.json configs 1/2: SigLIP-2-base-patch16-224 (D 768, head_dim 64, N 196), one block at full width
+    dict(name="base1_224", config="base-1layer", seed=9, batch=2, res=224, interp=False, taps=(1,)),
 ]
 
 GRAD_NAMES = [
@@ -77,6 +79,20 @@ def pack(prefix: str, t: torch.Tensor, out: dict):
         idx = np.linspace(0, a.size - 1, NSAMP).astype(np.int64)
         out[prefix + ".idx"] = idx
         out[prefix + ".samples"] = a[idx]
+
+
+def pack_err(prefix: str, t: torch.Tensor, rec: dict):
+    """Error statistics of a reduced-precision run of the REAL HF model against the fp32 values already packed
+    under `prefix`, on exactly the elements the fixture keeps (all of them, or the strided sample): the yardstick
+    for the HIP bf16 mode (tests assert HIP-bf16 error <= 2x these)."""
+    a = t.detach().to(torch.float32).contiguous().numpy().reshape(-1)
+    if prefix + ".full" in rec:
+        ref, got = rec[prefix + ".full"], a
+    else:
+        ref, got = rec[prefix + ".samples"], a[rec[prefix + ".idx"]]
+    e = got.astype(np.float64) - ref.astype(np.float64)
+    rec["bf16ac." + prefix + ".maxerr"] = np.float64(np.abs(e).max())
+    rec["bf16ac." + prefix + ".l2rel"] = np.float64(np.sqrt((e * e).sum()) / (np.sqrt((ref.astype(np.float64) ** 2).sum()) + 1e-30))
 
 
 def main():
@@ -117,6 +133,23 @@ def main():
         for n in GRAD_NAMES:
             if n in named and named[n].grad is not None:
                 pack("grad." + n, named[n].grad, rec)
+        # the reference trains and evaluates under torch.amp.autocast(bf16) (Siglip2sidafrozen.py:1375,
+        # hidf_video_classifier.py:389): the same HF model, same weights and input, under CPU bf16 autocast
+        hf.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ob = hf(pixel_values=x, output_hidden_states=True, interpolate_pos_encoding=case["interp"])
+            outb = {"pooler_output": ob.pooler_output.float(), "last_hidden_state": ob.last_hidden_state.float(),
+                    "hidden_states": tuple(h.float() for h in ob.hidden_states)}
+            lossb = oracle.probe_loss(outb, case["taps"])
+        lossb.backward()
+        pack_err("pooler_output", ob.pooler_output, rec)
+        pack_err("last_hidden_state", ob.last_hidden_state, rec)
+        for i, h in enumerate(ob.hidden_states):
+            pack_err(f"hidden_states.{i}", h, rec)
+        rec["bf16ac.loss"] = np.float64(lossb.item())
+        for n in GRAD_NAMES:
+            if n in named and named[n].grad is not None and ("grad." + n + ".shape") in rec:
+                pack_err("grad." + n, named[n].grad, rec)
         path = os.path.join(ROOT, "tests", "golden", case["name"] + ".npz")
         np.savez_compressed(path, **rec)
         print(f"wrote {path}: loss={loss.item():.6f} pooled|max|={o.pooler_output.abs().max().item():.4f} "

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["tiny_32", "tiny_48_interp", "hostile_42", "hostile_98_interp", "so400m1_384", "so400m1_224_interp"]
+CASES = ["tiny_32", "tiny_48_interp", "hostile_42", "hostile_98_interp", "so400m1_384", "so400m1_224_interp",
+         "base1_224"]
 SMALL_CASES = CASES[:4]
 
 
@@ -38,3 +39,15 @@ def compare(rec, prefix, tensor, atol, rtol):
     ref_scale = float(np.abs(ref).max())
     assert err <= atol + rtol * ref_scale, f"{prefix}: max|err| {err:.3e} > {atol} + {rtol}*{ref_scale:.3e}"
     return err, ref_scale
+
+
+def err_stats(rec, prefix, tensor):
+    """(max|err|, relative L2 error) against the fp32 golden values, on exactly the elements the fixture keeps — the same
+    statistic oracle/gen_golden.py stores under ``bf16ac.<prefix>.*`` for the real HF model under CPU bf16 autocast."""
+    a = np.asarray(tensor, dtype=np.float32).reshape(-1)
+    if prefix + ".full" in rec:
+        ref, got = rec[prefix + ".full"], a
+    else:
+        ref, got = rec[prefix + ".samples"], a[rec[prefix + ".idx"]]
+    e = got.astype(np.float64) - ref.astype(np.float64)
+    return float(np.abs(e).max()), float(np.sqrt((e * e).sum()) / (np.sqrt((ref.astype(np.float64) ** 2).sum()) + 1e-30))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg, hiplib):
         assert fn.argtypes is not None, f"{name} has no ctypes signature"
         assert len(fn.argtypes) == nargs, f"{name}: header has {nargs} parameters, binding {len(fn.argtypes)}"
     assert set(pkg.lib.declared_symbols()) == set(protos)
-    assert hiplib.sgl_abi_version() == 1
+    assert hiplib.sgl_abi_version() == 2
     assert hiplib.sgl_status_string(0) == b"ok" and hiplib.sgl_status_string(-3) == b"buffer too small"
 
 
@@ -121,10 +121,44 @@ def test_from_pretrained_local_dir_and_open_clip_factory_errors(pkg, tmp_path):
     save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
     m = pkg.SiglipVisionModelHIP.from_pretrained(str(d), compute_dtype="fp32")
     assert torch.equal(m.state_dict()["vision_model.head.probe"], sd["head.probe"])
-    m2 = pkg.SiglipVisionModelHIP.from_pretrained("tiny")
+    # a published google/siglip* file is the FULL SiglipModel: only the vision tower is kept (Siglip2sidafrozen.py:753)
+    full = {("vision_model." + k): v.contiguous() for k, v in sd.items()}
+    full.update({"text_model.embeddings.token_embedding.weight": torch.zeros(8, 4), "text_model.head.bias": torch.zeros(4),
+                 "logit_scale": torch.zeros(1), "logit_bias": torch.zeros(1)})
+    d2 = tmp_path / "full"
+    d2.mkdir()
+    (d2 / "config.json").write_text(json.dumps({"vision_config": cfg.to_dict(), "text_config": {"hidden_size": 4}}))
+    save_file(full, str(d2 / "model.safetensors"))
+    mf = pkg.SiglipVisionModelHIP.from_pretrained(str(d2), compute_dtype="fp32")
+    assert torch.equal(mf.state_dict()["vision_model.encoder.layers.1.mlp.fc1.weight"], sd["encoder.layers.1.mlp.fc1.weight"])
+    # a bare architecture name has no weights to load: an error, unless seeded random init is asked for (and then it warns)
+    with pytest.raises(OSError, match="allow_random_init"):
+        pkg.SiglipVisionModelHIP.from_pretrained("tiny")
+    with pytest.warns(UserWarning, match="RANDOM"):
+        m2 = pkg.SiglipVisionModelHIP.from_pretrained("tiny", allow_random_init=True)
     assert m2.config.num_hidden_layers == 3
     with pytest.raises(OSError):
         pkg.SiglipVisionModelHIP.from_pretrained("google/not-a-model")
+    with pytest.warns(UserWarning, match="RANDOM"):
+        pkg.create_model_and_transforms("tiny", pretrained="webli", device="cpu")
+    with pytest.warns(UserWarning, match="no-op"):
+        m2.gradient_checkpointing_enable()
+
+
+def test_custom_ops_are_registered_with_fake_impls(pkg):
+    """torch.ops.siglip_hip.encoder_fwd / encoder_bwd exist and their fake (meta) implementations give the right shapes
+    without touching a GPU (what torch.compile traces through; SURVEY.md 8b 'Who calls it')."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert hasattr(torch.ops.siglip_hip, "encoder_fwd") and hasattr(torch.ops.siglip_hip, "encoder_bwd")
+    cfg = pkg.get_config("tiny")
+    m = pkg.SiglipVisionModelHIP(cfg, "bf16")
+    params = m._flat_params()
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        x = torch.empty(2, 3, 32, 32)
+        outs = torch.ops.siglip_hip.encoder_fwd(x, params, m._handle, True, False, True, [1, 3], 0)
+    assert [tuple(o.shape) for o in outs[:4]] == [(2, 64), (2, 4, 64), (2, 4, 64), (2, 4, 64)]
+    assert outs[4].dtype == torch.uint8 and outs[4].numel() == m._sizes(2, 32, 32, True)[1]
+    assert tuple(outs[5].shape) == (2, 8, 64)          # 4 slots, 2 of them handed out as taps
 
 
 def test_adamw_plan_host_helper(hiplib):

@@ -1,6 +1,8 @@
-"""CPU: this repo's heads / decoder / losses / calibration against golden vectors produced by EXECUTING the
-reference's own class definitions (oracle/gen_golden_heads.py) and against the data files the reference ships
-(siglip/fusion_head.safetensors, freq_mlp.safetensors, coral_*.json — copied as fixtures to tests/golden/ref_siglip)."""
+"""This repo's heads / decoder / losses / calibration against golden vectors produced by EXECUTING the reference's own
+class definitions (oracle/gen_golden_heads.py) and against the data files the reference ships
+(siglip/fusion_head.safetensors, freq_mlp.safetensors, coral_*.json — copied as fixtures to tests/golden/ref_siglip).
+Every case runs twice: on the CPU (``-m "not gpu"``) and, marked ``gpu``, on the MI355X — the code that actually runs
+under these heads in training (PyTorch-ROCm kernels, plus the HIP depthwise stencil of csrc/decoder.hip in the decoder)."""
 import json
 import math
 import os
@@ -12,6 +14,11 @@ import torch
 import golden_util as gu
 
 REC = dict(np.load(os.path.join(gu.GOLDEN_DIR, "heads.npz")))
+
+
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def dev(request):
+    return request.param
 REF_SIGLIP = os.path.join(gu.GOLDEN_DIR, "ref_siglip")
 
 
@@ -37,81 +44,83 @@ def T(pkg, name, shape, bound=1.0, seed=0, offset=0.0):
 
 
 def close(got, ref, tol=2e-5):
-    got = np.asarray(got.detach().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
+    got = np.asarray(got.detach().cpu().numpy() if torch.is_tensor(got) else got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     err = np.abs(got - ref).max()
     assert err <= tol * max(1.0, np.abs(ref).max()), f"max|err| {err:.3e}"
 
 
-def test_mask_decoder_matches_reference(pkg):
+def test_mask_decoder_matches_reference(pkg, dev):
     B, g, D, E, K, S = (int(v) for v in REC["decoder.meta"])
     H = pkg.heads
-    taps = [T(pkg, f"tap{i}", (B, g * g, D)) for i in range(K)]
+    taps = [T(pkg, f"tap{i}", (B, g * g, D)).to(dev) for i in range(K)]
     for early_head in (False, True):   # reference order, and the HBM-saving head-before-upsample order
         dec = H.SegFormerMaskDecoder([D] * K, embed_dim=E, head_before_upsample=early_head).eval()
         seed_module(pkg, dec, "decoder.")
+        dec = dec.to(dev)
         close(dec(taps, (g, g), target_size=S), REC["decoder.out"], 5e-6 if not early_head else 2e-5)
 
 
-def test_segmentation_losses_match_reference(pkg):
+def test_segmentation_losses_match_reference(pkg, dev):
     H = pkg.heads
-    logits = T(pkg, "seg_logits", (3, 1, 24, 24), 3.0)
-    targets = (T(pkg, "seg_targets", (3, 1, 24, 24)) > 0.3).float()
+    logits = T(pkg, "seg_logits", (3, 1, 24, 24), 3.0).to(dev)
+    targets = (T(pkg, "seg_targets", (3, 1, 24, 24)) > 0.3).float().to(dev)
     for fn in ["focal_loss", "boundary_aware_loss", "morphological_loss", "iou_loss", "combined_segmentation_loss",
                "bce_dice_loss"]:
         close(getattr(H, fn)(logits, targets), REC["loss." + fn], 1e-6)
     dice, iou, pbin = H.dice_iou_from_logits(logits, targets)
-    close(np.asarray(dice), REC["loss.dice"], 1e-6)
-    close(np.asarray(iou), REC["loss.iou"], 1e-6)
+    close(torch.as_tensor(dice), REC["loss.dice"], 1e-6)
+    close(torch.as_tensor(iou), REC["loss.iou"], 1e-6)
     assert float(pbin.sum()) == float(REC["loss.pbin_sum"])
-    y = (T(pkg, "bin_targets", (16,)) > 0).float()
-    z = T(pkg, "bin_logits", (16,), 3.0)
+    y = (T(pkg, "bin_targets", (16,)) > 0).float().to(dev)
+    z = T(pkg, "bin_logits", (16,), 3.0).to(dev)
     close(H.FocalLoss(1.0, 2.0)(z, y), REC["loss.FocalLoss"], 1e-6)
-    close(H.FocalLoss(0.5, 1.5, pos_weight=torch.tensor(2.0))(z, y), REC["loss.FocalLoss_pw"], 1e-6)
+    close(H.FocalLoss(0.5, 1.5, pos_weight=torch.tensor(2.0, device=dev))(z, y), REC["loss.FocalLoss_pw"], 1e-6)
     close(H.label_smoothing_loss(z, y, 0.1), REC["loss.label_smoothing"], 1e-6)
 
 
 @pytest.mark.parametrize("size", ["tiny", "small", "medium", "large"])
-def test_cifake_head_matches_reference(pkg, size):
+def test_cifake_head_matches_reference(pkg, size, dev):
     dim = 128 if size == "large" else 64
     head = pkg.heads.CifakeBinaryHead(dim, model_size=size).eval()
     seed_module(pkg, head, f"cifake.{size}.")
-    feats = T(pkg, "cifake_features_large" if size == "large" else "cifake_features", (4, dim), 2.0)
+    head = head.to(dev)
+    feats = T(pkg, "cifake_features_large" if size == "large" else "cifake_features", (4, dim), 2.0).to(dev)
     close(head(feats), REC[f"cifake.{size}.logits"])
 
 
-def test_video_and_se_heads_match_reference(pkg):
+def test_video_and_se_heads_match_reference(pkg, dev):
     vid = pkg.heads.VideoBinaryHead(64, num_frames=4).eval()
     seed_module(pkg, vid, "video.")
-    close(vid(T(pkg, "video_features", (12, 64), 2.0), batch_size=3), REC["video.logits"])
+    close(vid.to(dev)(T(pkg, "video_features", (12, 64), 2.0).to(dev), batch_size=3), REC["video.logits"])
     dim = int(REC["se.dim"])
     se = pkg.heads.SEBinaryHead(dim).eval()
     seed_module(pkg, se, "se.")
-    close(se(T(pkg, "se_features", (3, dim), 2.0)), REC["se.logits"])
+    close(se.to(dev)(T(pkg, "se_features", (3, dim), 2.0).to(dev)), REC["se.logits"])
 
 
-def test_fusion_and_freq_match_reference(pkg):
+def test_fusion_and_freq_match_reference(pkg, dev):
     H = pkg.heads
     fm = H.FreqMLPv5().eval()
     seed_module(pkg, fm, "freqv5.")
-    close(fm(T(pkg, "freq_in", (5, 24), 2.0)), REC["freqv5.logits"])
+    close(fm.to(dev)(T(pkg, "freq_in", (5, 24), 2.0).to(dev)), REC["freqv5.logits"])
     af = H.AdaptiveFusionHead().eval()
     seed_module(pkg, af, "afusion.")
-    close(af(T(pkg, "zf", (7,), 3.0), T(pkg, "zs", (7,), 3.0)), REC["afusion.z"])
-    close(np.asarray(H.fit_coral_cutpoints(T(pkg, "coral_fit_logits", (257,), 4.0))), REC["coral.fit_cuts"], 1e-7)
+    close(af.to(dev)(T(pkg, "zf", (7,), 3.0).to(dev), T(pkg, "zs", (7,), 3.0).to(dev)), REC["afusion.z"])
+    close(np.asarray(H.fit_coral_cutpoints(T(pkg, "coral_fit_logits", (257,), 4.0).to(dev))), REC["coral.fit_cuts"], 1e-7)
 
 
-def test_shipped_artifacts_known_answers(pkg):
+def test_shipped_artifacts_known_answers(pkg, dev):
     """The weights / calibration files the reference ships, run through this repo's modules."""
     from safetensors.torch import load_file
     H = pkg.heads
     fh = H.LinearFusionHead()
     fh.load_state_dict(load_file(os.path.join(REF_SIGLIP, "fusion_head.safetensors")))
-    close(fh(T(pkg, "fusion_probs", (6, 2), 0.5, 0, 0.5)), REC["shipped.fusion_out"], 1e-6)
+    close(fh.to(dev)(T(pkg, "fusion_probs", (6, 2), 0.5, 0, 0.5).to(dev)), REC["shipped.fusion_out"], 1e-6)
     fa = H.FreqMLPApp()
     fa.load_state_dict(load_file(os.path.join(REF_SIGLIP, "freq_mlp.safetensors")))
-    close(fa(T(pkg, "freq_in", (5, 24), 2.0)), REC["shipped.freq_out"], 1e-5)
+    close(fa.to(dev)(T(pkg, "freq_in", (5, 24), 2.0).to(dev)), REC["shipped.freq_out"], 1e-5)
     cuts = json.load(open(os.path.join(REF_SIGLIP, "coral_cutpoints.json")))
     cc = H.CoralCalibrator(cuts)
     close(cc.c, REC["shipped.coral_c"], 1e-6)
@@ -119,19 +128,19 @@ def test_shipped_artifacts_known_answers(pkg):
     got = np.stack([cc.probs(float(z)).numpy() for z in zs])
     close(got, REC["shipped.coral_probs"], 1e-6)
     assert [cc.predict(float(z))[0] for z in zs] == [int(i) for i in REC["shipped.coral_idx"]]
-    close(cc.probs_batch(torch.tensor(zs, dtype=torch.float32)), REC["shipped.coral_probs"], 1e-6)
+    close(cc.probs_batch(torch.tensor(zs, dtype=torch.float32, device=dev)), REC["shipped.coral_probs"], 1e-6)
     temp = json.load(open(os.path.join(REF_SIGLIP, "coral_temp.json")))["temperature"]
     assert abs(temp - float(REC["shipped.coral_temp"])) < 1e-12 and len(H.RISK_NAMES) == 5
 
 
-def test_mtl_loss_and_shapes(pkg):
+def test_mtl_loss_and_shapes(pkg, dev):
     H = pkg.heads
-    cls = T(pkg, "cls", (4, 3), 2.0)
-    seg = T(pkg, "seg", (4, 1, 16, 16), 2.0)
-    y = torch.tensor([0, 1, 2, 1])
-    m = (T(pkg, "m", (4, 1, 16, 16)) > 0).float()
-    hm = torch.tensor([True, False, True, True])
+    cls = T(pkg, "cls", (4, 3), 2.0).to(dev)
+    seg = T(pkg, "seg", (4, 1, 16, 16), 2.0).to(dev)
+    y = torch.tensor([0, 1, 2, 1], device=dev)
+    m = (T(pkg, "m", (4, 1, 16, 16)) > 0).float().to(dev)
+    hm = torch.tensor([True, False, True, True], device=dev)
     base = torch.nn.functional.cross_entropy(cls, y)
-    assert torch.allclose(H.mtl_loss(cls, seg, y, m, torch.zeros(4, dtype=torch.bool)), base)
+    assert torch.allclose(H.mtl_loss(cls, seg, y, m, torch.zeros(4, dtype=torch.bool, device=dev)), base)
     full = H.mtl_loss(cls, seg, y, m, hm, lam_seg=0.7)
     assert torch.allclose(full, base + 0.7 * H.bce_dice_loss(seg[hm], m[hm]))
