@@ -335,6 +335,62 @@ int sgl_prepare_weights(sgl_ctx* ctx, const sgl_weights* w, void* shadow, size_t
   return sgl_prepare_weights_dirty(ctx, w, shadow, shadow_bytes, nullptr, 1, stream);
 }
 
+
+// Where each master tensor's copies live in the shadow arena (the destinations sgl_prepare_weights_dirty casts into),
+// matched by the master pointer: lets the optimizer write them in its own pass (optimizer.hip, adamw_ex_kernel).
+int sgl_adamw_bind_shadows(const sgl_ctx* ctx, const sgl_weights* w, void* shadow, const sgl_adamw_tensor* table,
+                           sgl_adamw_aux* aux, int ntensors) {
+  if (!ctx || !w || !shadow || !table || !aux) return SGL_ERR_NULL;
+  const int D = ctx->D, I = ctx->I, Ip = ctx->Ip;
+  const size_t es = ctx->es;
+  int bound = 0;
+  auto mat = [&](const float* master, int rows, int cols, int row0, size_t off, int ld, size_t off_t, int ld_t,
+                 size_t elem_off = 0, size_t elem_off_t = 0) {
+    if (!master) return;
+    for (int i = 0; i < ntensors; ++i)
+      if (table[i].p == master) {
+        aux[i].dst = at(shadow, off) + elem_off * es;
+        aux[i].dst_t = ld_t ? at(shadow, off_t) + elem_off_t * es : nullptr;
+        aux[i].dst_f32 = nullptr;
+        aux[i].ld = ld; aux[i].ld_t = ld_t; aux[i].rows = rows; aux[i].cols = cols; aux[i].row0 = row0;
+        aux[i].dtype = ctx->dt;
+        ++bound;
+      }
+  };
+  auto vec = [&](const float* master, size_t off, size_t elem_off) {
+    if (!master) return;
+    for (int i = 0; i < ntensors; ++i)
+      if (table[i].p == master) {
+        aux[i].dst = aux[i].dst_t = nullptr;
+        aux[i].dst_f32 = reinterpret_cast<float*>(at(shadow, off)) + elem_off;
+        ++bound;
+      }
+  };
+  mat(w->patch_w, D, ctx->K0, 0, ctx->sh_wpatch, ctx->Kp, 0, 0);
+  for (int l = 0; l < ctx->L && w->layers; ++l) {
+    const sgl_layer_weights& lw = w->layers[l];
+    const ShadowLayer& sl = ctx->sh_layers[l];
+    const float* qkv_w[3] = {lw.q_w, lw.k_w, lw.v_w};
+    const float* qkv_b[3] = {lw.q_b, lw.k_b, lw.v_b};
+    for (int j = 0; j < 3; ++j) {
+      mat(qkv_w[j], D, D, 0, sl.wqkv, D, sl.wqkv_t, 3 * D, (size_t)j * D * D, (size_t)j * D);
+      vec(qkv_b[j], sl.bqkv, (size_t)j * D);
+    }
+    mat(lw.o_w, D, D, 0, sl.wo, D, sl.wo_t, D);
+    mat(lw.fc1_w, I, D, 0, sl.w1, D, sl.w1_t, Ip);
+    mat(lw.fc2_w, D, I, 0, sl.w2, Ip, sl.w2_t, D);
+    vec(lw.fc1_b, sl.b1, 0);
+  }
+  if (ctx->cfg.use_head) {
+    mat(w->in_proj_w, 3 * D, D, D, ctx->sh_hwkv, D, ctx->sh_hwkv_t, 2 * D);
+    mat(w->out_proj_w, D, D, 0, ctx->sh_hwo, D, ctx->sh_hwo_t, D);
+    mat(w->head_fc1_w, I, D, 0, ctx->sh_hw1, D, ctx->sh_hw1_t, Ip);
+    mat(w->head_fc2_w, D, I, 0, ctx->sh_hw2, Ip, ctx->sh_hw2_t, D);
+    vec(w->head_fc1_b, ctx->sh_hb1, 0);
+  }
+  return bound;
+}
+
 // -------------------------------------------------------------------------------------------------------
 int sgl_forward_ex(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, const float* pixels, int channels_last, int B,
                    int H, int W, int interpolate_pos, float* hidden_states, int hs_slots, float* last_hidden,

@@ -147,6 +147,199 @@ __global__ __launch_bounds__(256) void adamw_kernel(const sgl_adamw_tensor* __re
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// AdamW + everything that must follow a parameter update, in the same pass over the parameter (SURVEY.md §8f row 3,
+// kernel work-list k11): the compute-dtype weight shadow the GEMMs read (row-major copy, zero-padded leading dimension),
+// its transpose (the dX GEMMs' "B" operand), fp32 bias copies, and the CiFake trainer's weight EMA
+// (cifake_binary_classifier.py:222-225).  Replaces the per-step cast_pad / cast_transpose launches of
+// sgl_prepare_weights (what autocast re-does every step in the reference, Siglip2sidafrozen.py:1375): +4 B/parameter of
+// stores here instead of a 6 B/parameter read-modify pass of their own.
+//
+// Matrices with a shadow are walked in 64x64 tiles (one tile per 256-thread block: 4 x 16-byte accesses per thread per
+// array, 256-byte row segments), the bf16 tile is transposed through LDS so that both copies are written in >= 128-byte
+// row segments.  Everything else uses the linear 4096-element chunks of adamw_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+struct GroupHyper {
+  float lr[16], wd[16];
+  int n;
+};
+
+template <typename T> __device__ __forceinline__ T cvt_out(float x);
+template <> __device__ __forceinline__ float cvt_out<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 cvt_out<bf16>(float x) { return (bf16)x; }
+
+template <typename T>
+__device__ __forceinline__ void adamw_tile(const sgl_adamw_tensor& t, const sgl_adamw_aux& a, int tile, float lr,
+                                           float wd, float gs, const AdamConst& c, float ema_decay, T* lt /*[64][66]*/) {
+  const int cols = a.cols, rows = a.rows;
+  const int tiles_c = (cols + 63) >> 6;
+  const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool vec = ((cols & 3) == 0) && aligned16(t.p, t.g, t.m, t.v) && (!a.ema || ((((uintptr_t)a.ema) & 15) == 0));
+  T* dst = reinterpret_cast<T*>(a.dst);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 16 * k, cc = c0 + tx * 4;
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && cc < cols) {
+      const size_t i = (size_t)r * cols + cc;
+      if (vec && cc + 3 < cols) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(t.p + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
+        f32x4 m = *reinterpret_cast<const f32x4*>(t.m + i);
+        f32x4 v = *reinterpret_cast<const f32x4*>(t.v + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float pj = p[j], mj = m[j], vj = v[j];
+          adamw_one(pj, g[j] * gs, mj, vj, lr, wd, c);
+          p[j] = pj; m[j] = mj; v[j] = vj; out[j] = pj;
+        }
+        *reinterpret_cast<f32x4*>(t.p + i) = p;
+        *reinterpret_cast<f32x4*>(t.m + i) = m;
+        *reinterpret_cast<f32x4*>(t.v + i) = v;
+        if (a.ema) {
+          const f32x4 e = *reinterpret_cast<const f32x4*>(a.ema + i);
+          *reinterpret_cast<f32x4*>(a.ema + i) = e * ema_decay + p * (1.0f - ema_decay);
+        }
+      } else {
+        for (int j = 0; j < 4 && cc + j < cols; ++j) {
+          adamw_one(t.p[i + j], t.g[i + j] * gs, t.m[i + j], t.v[i + j], lr, wd, c);
+          out[j] = t.p[i + j];
+          if (a.ema) a.ema[i + j] = a.ema[i + j] * ema_decay + out[j] * (1.0f - ema_decay);
+        }
+      }
+      if (dst && r >= a.row0) {
+        T* d = dst + (size_t)(r - a.row0) * a.ld + cc;
+        if (cc + 3 < cols && ((((uintptr_t)d) & (4 * sizeof(T) - 1)) == 0)) {
+          T o4[4] = {cvt_out<T>(out[0]), cvt_out<T>(out[1]), cvt_out<T>(out[2]), cvt_out<T>(out[3])};
+          if constexpr (sizeof(T) == 2) {
+            u32x2 w;
+            __builtin_memcpy(&w, o4, 8);
+            *reinterpret_cast<u32x2*>(d) = w;
+          } else {
+            u32x4 w;
+            __builtin_memcpy(&w, o4, 16);
+            *reinterpret_cast<u32x4*>(d) = w;
+          }
+        } else {
+          for (int j = 0; j < 4 && cc + j < cols; ++j) d[j] = cvt_out<T>(out[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lt[(ty + 16 * k) * 66 + tx * 4 + j] = cvt_out<T>(out[j]);
+  }
+  if (!a.dst_t) return;
+  __syncthreads();
+  // transposed copy: output row = parameter column c0 + oc, 64 consecutive elements = parameter rows r0 .. r0+63
+  T* dt = reinterpret_cast<T*>(a.dst_t);
+  const int oc = threadIdx.x >> 2, seg = threadIdx.x & 3;   // 64 output rows x 4 segments of 16 elements
+  if (c0 + oc < cols) {
+    const int rb = r0 + seg * 16;
+    T* drow = dt + (size_t)(c0 + oc) * a.ld_t + (rb - a.row0);
+    T vals[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vals[j] = lt[(seg * 16 + j) * 66 + oc];
+    if (rb >= a.row0 && rb + 15 < rows && ((((uintptr_t)drow) & 15) == 0)) {
+      // 16 consecutive elements of one output row: 16-byte stores
+      constexpr int PER = 16 / sizeof(T);
+#pragma unroll
+      for (int q = 0; q < 16 / PER; ++q) {
+        u32x4 w;
+        __builtin_memcpy(&w, &vals[q * PER], 16);
+        *reinterpret_cast<u32x4*>(drow + q * PER) = w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (rb + j < rows && rb + j >= a.row0) drow[j] = vals[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_ex_kernel(const sgl_adamw_tensor* __restrict__ T,
+                                                       const sgl_adamw_aux* __restrict__ A,
+                                                       const int32_t* __restrict__ map, AdamConst c, GroupHyper gh,
+                                                       const float* __restrict__ clip, float ema_decay) {
+  __shared__ float lds_tile[64 * 66];
+  const int ti = map[2 * blockIdx.x], ch = map[2 * blockIdx.x + 1];
+  const sgl_adamw_tensor t = T[ti];
+  if (!t.g) return;
+  const sgl_adamw_aux a = A[ti];
+  const float gs = clip ? clip[1] : 1.0f;
+  const float lr = (gh.n > 0 && a.group >= 0 && a.group < gh.n) ? gh.lr[a.group] : t.lr;
+  const float wd = (gh.n > 0 && a.group >= 0 && a.group < gh.n) ? gh.wd[a.group] : t.weight_decay;
+  if (a.dst || a.dst_t) {  // tiled matrix with shadow copies
+    if (a.dtype == SGL_DTYPE_BF16)
+      adamw_tile<bf16>(t, a, ch, lr, wd, gs, c, ema_decay, reinterpret_cast<bf16*>(lds_tile));
+    else
+      adamw_tile<float>(t, a, ch, lr, wd, gs, c, ema_decay, lds_tile);
+    return;
+  }
+  const uint64_t base = (uint64_t)ch * OPT_CHUNK;
+  // linear chunk: 1-D tensors and matrices without shadows
+  const bool vec = aligned16(t.p, t.g, t.m, t.v) && (!a.ema || ((((uintptr_t)a.ema) & 15) == 0)) &&
+                   (!a.dst_f32 || ((((uintptr_t)a.dst_f32) & 15) == 0));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t i = base + (uint64_t)(k * 256 + threadIdx.x) * 4;
+    if (vec && i + 3 < t.n) {
+      f32x4 p = *reinterpret_cast<const f32x4*>(t.p + i);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(t.g + i);
+      f32x4 m = *reinterpret_cast<const f32x4*>(t.m + i);
+      f32x4 v = *reinterpret_cast<const f32x4*>(t.v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pj = p[j], mj = m[j], vj = v[j];
+        adamw_one(pj, g[j] * gs, mj, vj, lr, wd, c);
+        p[j] = pj; m[j] = mj; v[j] = vj;
+      }
+      *reinterpret_cast<f32x4*>(t.p + i) = p;
+      *reinterpret_cast<f32x4*>(t.m + i) = m;
+      *reinterpret_cast<f32x4*>(t.v + i) = v;
+      if (a.dst_f32) *reinterpret_cast<f32x4*>(a.dst_f32 + i) = p;
+      if (a.ema) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(a.ema + i);
+        *reinterpret_cast<f32x4*>(a.ema + i) = e * ema_decay + p * (1.0f - ema_decay);
+      }
+    } else {
+      for (uint64_t j = i; j < t.n && j < i + 4; ++j) {
+        adamw_one(t.p[j], t.g[j] * gs, t.m[j], t.v[j], lr, wd, c);
+        if (a.dst_f32) a.dst_f32[j] = t.p[j];
+        if (a.ema) a.ema[j] = a.ema[j] * ema_decay + t.p[j] * (1.0f - ema_decay);
+      }
+    }
+  }
+}
+
+// out[0] = s*||g||_2 ; out[1] = s*min(1, max_norm / (s*norm + 1e-6)): the factor every gradient is multiplied by when the
+// stored gradients are rank SUMS and s = 1/world (ddp.GradBucketReducer(average="defer")); s = 1 is grad_norm_finish.
+__global__ __launch_bounds__(1024) void grad_norm_finish_scaled_kernel(const float* __restrict__ partial, int n,
+                                                                       float max_norm, float gscale,
+                                                                       float* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    const float norm = (float)sqrt(t) * gscale;
+    out[0] = norm;
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);
+      if (coef > 1.0f) coef = 1.0f;
+    }
+    out[1] = coef * gscale;
+  }
+}
+
 // shadow <- shadow*decay + p*(1-decay) for every table entry (p = .p, shadow = .m); the reference's
 // ExponentialMovingAverage.update (cifake_binary_classifier.py:222-225) as one launch.  12 B/parameter.
 __global__ __launch_bounds__(256) void ema_kernel(const sgl_adamw_tensor* __restrict__ T,
@@ -213,6 +406,44 @@ int sgl_op_grad_norm(const sgl_adamw_tensor* table, const int32_t* blockmap, int
   if (nblocks > 0) hipLaunchKernelGGL(sgl::grad_sqnorm_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, table, blockmap, partials);
   hipLaunchKernelGGL(sgl::grad_norm_finish_kernel, dim3(1), dim3(1024), 0, s, partials, (int)nblocks, max_norm,
                      norm_and_coef);
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
+
+
+int sgl_op_grad_norm_scaled(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, float max_norm,
+                            float grad_scale, float* partials, float* norm_and_coef, sgl_stream stream) {
+  if (!table || !blockmap || !partials || !norm_and_coef) return SGL_ERR_NULL;
+  if (nblocks < 0 || nblocks > 0x7fffffff) return SGL_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (nblocks > 0) hipLaunchKernelGGL(sgl::grad_sqnorm_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, table, blockmap, partials);
+  hipLaunchKernelGGL(sgl::grad_norm_finish_scaled_kernel, dim3(1), dim3(1024), 0, s, partials, (int)nblocks, max_norm,
+                     grad_scale, norm_and_coef);
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
+
+int sgl_op_adamw_ex(const sgl_adamw_tensor* table, const sgl_adamw_aux* aux, const int32_t* blockmap, int64_t nblocks,
+                    double beta1, double beta2, double eps, int step, const float* norm_and_coef,
+                    const float* group_lr_wd_host, int ngroups, double ema_decay, sgl_stream stream) {
+  if (!table || !aux || !blockmap) return SGL_ERR_NULL;
+  if (nblocks < 0 || nblocks > 0x7fffffff || step < 1 || ngroups < 0 || ngroups > 16) return SGL_ERR_BAD_SHAPE;
+  if (ngroups > 0 && !group_lr_wd_host) return SGL_ERR_NULL;
+  if (nblocks == 0) return SGL_OK;
+  sgl::AdamConst c;
+  c.omb1 = (float)(1.0 - beta1);
+  c.beta2 = (float)beta2;
+  c.omb2 = (float)(1.0 - beta2);
+  c.eps = (float)eps;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  c.inv_bc1 = (float)(1.0 / bc1);
+  c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  sgl::GroupHyper gh;
+  gh.n = ngroups;
+  for (int i = 0; i < 16; ++i) {
+    gh.lr[i] = i < ngroups ? group_lr_wd_host[2 * i] : 0.f;
+    gh.wd[i] = i < ngroups ? group_lr_wd_host[2 * i + 1] : 0.f;
+  }
+  hipLaunchKernelGGL(sgl::adamw_ex_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, table, aux,
+                     blockmap, c, gh, norm_and_coef, (float)ema_decay);
   return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
 }
 

@@ -1,34 +1,60 @@
 """Data-parallel gradient exchange for the encoder path: one process per GPU, RCCL over xGMI
-(``torch.distributed`` backend ``"nccl"`` is RCCL on ROCm), gradient buckets all-reduced while the backward
-of the blocks below is still running.
+(``torch.distributed`` backend ``"nccl"`` is RCCL on ROCm), gradients all-reduced while the backward of the
+blocks below is still running.
 
 The reference has no working distributed path (an un-initialised FSDP wrapper only); the
 exchange pattern here is designed for the MI355X node: images are independent, so the only
-collective is the sum-all-reduce of parameter gradients.  The encoder's backward hands over one flat fp32
-bucket per transformer block (≈61 MB for so400m) the moment that block's gradients are complete
-(``encoder._EncoderFn.backward``); ``reduce_bucket`` launches the all-reduce asynchronously on the process
-group's own stream, and ``finish`` makes the compute stream wait for all of them and applies the 1/world
-average.  Buckets are large (tens of MB) so each ring step moves big messages over the point-to-point xGMI
-links rather than many small ones.
+collective is the sum of parameter gradients.
+
+* **Few, large messages.**  The encoder's backward produces one flat fp32 gradient bucket per transformer block
+  (61 MB for so400m); consecutive blocks share one allocation (``SiglipVisionModelHIP._grad_buckets`` carves a *chunk* of
+  ``ceil(groups / max_buckets)`` blocks out of one tensor), and the chunk is handed to ``reduce_bucket`` the moment its
+  last block is complete: 8 collectives of ≈0.2 GB per step for so400m instead of 29 of 61 MB.  xGMI is point-to-point
+  (7 links × ≈153 GB/s per GPU), so a ring step is bound by one link: big messages amortise the per-step latency.
+* **Wire format.**  ``wire="fp32"`` (default): one in-place sum all-reduce per chunk, exact.  ``wire="bf16"``: the
+  full-mesh form of SURVEY.md §8e — every rank sends shard *j* of its bf16-rounded gradients straight to rank *j*
+  (``all_to_all_single``: 7 peers, 7 different links), sums the ``world`` shards it received **in fp32**, and the reduced
+  shard goes back as bf16 (``all_gather_into_tensor``): half the bytes of the fp32 ring, one rounding of the inputs and one
+  of the mean, no bf16 accumulation chain.
+* **1/world.**  ``average=True`` scales all chunks with ONE ``torch._foreach_mul_`` in ``finish()``;
+  ``average="defer"`` leaves sums in ``.grad`` and the consumer applies the factor: ``FusedAdamW(grad_scale=1/world)``
+  folds it into the clip coefficient it already multiplies every gradient by (no extra pass over the gradients).
+* ``no_sync()`` suppresses the exchange for gradient-accumulation micro-steps; ``reduce_grads`` (everything outside the
+  encoder: decoder, heads) is asynchronous and completed by ``finish()`` as well.
+
+Nothing here has been timed on more than one GPU by the builder (the 8-GPU node is the driver's): correctness is covered by
+world-2 gloo tests, the scaling curve is whatever the driver's SCALE run measures.
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional
+import contextlib
+from typing import Iterable, Optional, Union
 
 import torch
 import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, average: bool = True):
+    def __init__(self, process_group: Optional["dist.ProcessGroup"] = None, average: Union[bool, str] = True,
+                 wire: str = "fp32", max_buckets: int = 8):
+        if wire not in ("fp32", "bf16"):
+            raise ValueError("wire must be 'fp32' or 'bf16'")
+        if average not in (True, False, "defer"):
+            raise ValueError("average must be True, False or 'defer'")
         self.pg = process_group
         self.average = average
-        self._pending: list[tuple[torch.Tensor, object]] = []
+        self.wire = wire
+        self.max_buckets = int(max_buckets)
+        self._sync = True
+        self._pending: list = []          # (kind, flat, work, extra)
+        self._heads: list = []            # (flat, params) of reduce_grads calls in flight
+        self.collectives_issued = 0       # statistics for tests / bench
 
     # ---- wiring ------------------------------------------------------------------------------------------
     def attach(self, encoder_module) -> "GradBucketReducer":
-        """Make ``encoder_module`` (a ``SiglipVisionModelHIP``) call back into this reducer per bucket."""
+        """Make ``encoder_module`` (a ``SiglipVisionModelHIP``) call back into this reducer per gradient chunk."""
         encoder_module._grad_reducer = self
+        encoder_module._bucket_cache = {}
         return self
 
     def world_size(self) -> int:
@@ -36,39 +62,89 @@ class GradBucketReducer:
             return 1
         return dist.get_world_size(self.pg)
 
+    @property
+    def grad_scale(self) -> float:
+        """What the consumer must multiply gradients by (1/world when average='defer', else 1)."""
+        return 1.0 / self.world_size() if self.average == "defer" else 1.0
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient-accumulation micro-steps: backward runs without any collective; the step that leaves the context
+        exchanges the accumulated ``.grad`` through ``reduce_grads`` / its own backward."""
+        prev, self._sync = self._sync, False
+        try:
+            yield self
+        finally:
+            self._sync = prev
+
     # ---- called from the encoder's backward -----------------------------------------------------------------
     def reduce_bucket(self, flat: torch.Tensor) -> None:
-        if self.world_size() == 1:
+        """Start the exchange of one flat fp32 gradient chunk (asynchronous; completed by ``finish``)."""
+        world = self.world_size()
+        if world == 1 or not self._sync:
             return
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append((flat, work))
+        self.collectives_issued += 1
+        if self.wire == "fp32":
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._pending.append(("ar", flat, work, None))
+            return
+        # bf16 wire, fp32 accumulate: all-to-all of bf16 shards -> local fp32 sum -> all-gather of the bf16 result
+        n = flat.numel()
+        shard = (n + world - 1) // world
+        send = torch.zeros(world * shard, dtype=torch.bfloat16, device=flat.device)
+        send[:n].copy_(flat)
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, group=self.pg, async_op=True)
+        self._pending.append(("a2a", flat, work, (send, recv, shard)))
 
     def finish(self) -> None:
-        """Order every outstanding all-reduce before whatever the current stream does next (no host sync on
-        the NCCL/RCCL backend) and turn sums into means."""
-        if not self._pending:
+        """Order every outstanding collective before whatever the current stream does next (no host sync on the
+        NCCL/RCCL backend) and, with average=True, turn sums into means with one multi-tensor launch."""
+        if not self._pending and not self._heads:
             return
-        scale = 1.0 / self.world_size()
-        for flat, work in self._pending:
+        world = self.world_size()
+        done: list[torch.Tensor] = []
+        gathers = []
+        for kind, flat, work, extra in self._pending:
             work.wait()
-            if self.average:
-                flat.mul_(scale)
+            if kind == "ar":
+                done.append(flat)
+                continue
+            send, recv, shard = extra
+            red = recv.view(world, shard).float().sum(0).to(torch.bfloat16)       # fp32 accumulation of the world shards
+            out = send                                                                # reuse as the gather destination
+            gathers.append((flat, out, dist.all_gather_into_tensor(out, red, group=self.pg, async_op=True), red))
+        for flat, out, work, _red in gathers:
+            work.wait()
+            flat.copy_(out[:flat.numel()])
+            done.append(flat)
         self._pending.clear()
+        for flat, params, work in self._heads:
+            work.wait()
+            done.append(flat)
+        if self.average is True and done:
+            torch._foreach_mul_(done, 1.0 / world)
+        for flat, params, _ in self._heads:
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._heads.clear()
 
     # ---- everything outside the encoder (heads, decoder): one bucket after backward ---------------------------
-    def reduce_grads(self, params: Iterable[torch.nn.Parameter]) -> None:
+    def reduce_grads(self, params: Iterable[torch.nn.Parameter], async_op: bool = False) -> None:
+        """Sum (and average) the ``.grad`` of parameters outside the encoder as ONE flat message.  ``async_op=True``
+        returns right after launching the collective; ``finish()`` completes it and writes the results back."""
         ps = [p for p in params if p.grad is not None]
-        if not ps or self.world_size() == 1:
+        if not ps or self.world_size() == 1 or not self._sync:
             return
         flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
-        if self.average:
-            flat.mul_(1.0 / self.world_size())
-        off = 0
-        for p in ps:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        self.collectives_issued += 1
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._heads.append((flat, ps, work))
+        if not async_op:
+            self.finish()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

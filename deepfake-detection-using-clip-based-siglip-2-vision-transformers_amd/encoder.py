@@ -217,8 +217,9 @@ def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Te
                 hs_rest: torch.Tensor, params: Sequence[torch.Tensor], handle: int, image_hw: Sequence[int],
                 interp: bool, want_pooled: bool, tap_ids: Sequence[int], needs: Sequence[bool]) -> List[torch.Tensor]:
     """sgl_backward_begin_p -> sgl_backward_layer_p (L-1 ... first trainable block) -> sgl_backward_embed.
-    grads = [d pooled, d last_hidden_state, d tap...] (None = no gradient).  Returns one tensor per parameter (views of
-    one flat fp32 bucket per block / group — the DDP all-reduce unit; an empty tensor where needs[i] is False)."""
+    grads = [d pooled, d last_hidden_state, d tap...] (None = no gradient).  Returns the flat fp32 gradient chunks of
+    ``SiglipVisionModelHIP._bucket_layout(needs)`` (the DDP all-reduce units); the autograd formula slices the
+    per-parameter views out of them outside the op, so no output of the op aliases another."""
     mod = _module_of(handle)
     lib = _lib.load()
     cfg = mod.config
@@ -253,9 +254,26 @@ def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Te
             k += 1
 
     with torch.cuda.device(dev):
-        grads_out, buckets, groups = mod._grad_buckets(needs, dev)
-        if d_pooled is None and "head" in buckets:
-            buckets["head"].zero_()      # the C side skips the pooling head (and post-LN when d_last is None too)
+        chunks, groups = mod._bucket_layout(needs)
+        flats = mod._alloc_buckets(chunks, dev)
+        grads_out = [None] * len(params)
+        chunk_of, last_of = {}, {}
+        for ci, (total, members, entries) in enumerate(chunks):
+            for i, off, n in entries:
+                grads_out[i] = flats[ci][off:off + n]
+            for grp in members:
+                chunk_of[grp] = ci
+            last_of[ci] = members[-1]
+        if d_pooled is None and "head" in groups:     # the C side skips the pooling head (and post-LN when d_last is None too)
+            for i in groups["head"]:
+                grads_out[i].zero_()
+        reducer = mod._grad_reducer
+
+        def group_done(grp):
+            """Hand a chunk to the reducer once its last group (in completion order) is complete."""
+            if reducer is not None and grp in chunk_of and last_of[chunk_of[grp]] == grp:
+                reducer.reduce_bucket(flats[chunk_of[grp]])
+
         gl = (_lib.SglLayerPtrs * max(L, 1))()
         g = _lib.SglGrads()
         g.layers = C.cast(gl, C.POINTER(_lib.SglLayerPtrs))
@@ -275,36 +293,32 @@ def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Te
         ws = mod._workspace(sizes[2], dev)
         stream = _lib.current_stream_handle()
         shadow, wts = mod._shadow, mod._weights_struct
-        reducer = mod._grad_reducer
         st = lib.sgl_backward_begin_p(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), B, H, W, hs_ptr[L],
                                       _lib.ptr(d_last), _lib.ptr(d_pooled), _lib.ptr(tap_grads[L]),
                                       saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
         _lib.check(st, "sgl_backward_begin_p", mod._ctx)
-        if reducer is not None and "head" in buckets:
-            reducer.reduce_bucket(buckets["head"])
+        group_done("head")
         for l in range(L - 1, stop - 1, -1):
             need_dx = 1 if (l > stop or train_emb) else 0
             st = lib.sgl_backward_layer_p(mod._ctx, C.byref(wts), shadow.data_ptr(), C.byref(g), l, B, H, W, hs_ptr[l],
                                           _lib.ptr(tap_grads[l]), need_dx, saved.data_ptr(), sizes[1], ws.data_ptr(),
                                           sizes[2], stream)
             _lib.check(st, f"sgl_backward_layer_p[{l}]", mod._ctx)
-            if reducer is not None and f"layer{l}" in buckets:
-                reducer.reduce_bucket(buckets[f"layer{l}"])
+            group_done(f"layer{l}")
         if train_emb:
             st = lib.sgl_backward_embed(mod._ctx, C.byref(wts), C.byref(g), B, H, W, 1 if interp else 0,
                                         saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
             _lib.check(st, "sgl_backward_embed", mod._ctx)
-            if reducer is not None:
-                reducer.reduce_bucket(buckets["emb"])
+            group_done("emb")
         if reducer is not None:
             reducer.finish()
-    empty = saved.new_empty((0,), dtype=torch.float32)
-    return [empty if t is None else t for t in grads_out]
+    return flats
 
 
 @encoder_bwd.register_fake
 def _(grads, taps, saved, hs_rest, params, handle, image_hw, interp, want_pooled, tap_ids, needs):
-    return [torch.empty_like(p) if n else p.new_empty((0,)) for p, n in zip(params, needs)]
+    chunks, _ = _module_of(handle)._bucket_layout(needs)
+    return [saved.new_empty((total,), dtype=torch.float32) for total, _, _ in chunks]
 
 
 def _encoder_setup_context(ctx, inputs, output):
@@ -332,9 +346,14 @@ def _encoder_backward(ctx, grads):
     taps, saved, hs_rest, params = list(saved_t[:nt]), saved_t[nt], saved_t[nt + 1], list(saved_t[nt + 2:])
     needs = [bool(n) for n in ctx.needs_input_grad[1]] if isinstance(ctx.needs_input_grad[1], (list, tuple)) \
         else [p.requires_grad for p in params]
-    out = torch.ops.siglip_hip.encoder_bwd(list(grads[:2 + nt]), taps, saved, hs_rest, params, ctx.handle, ctx.image_hw,
-                                           ctx.interp, ctx.want_pooled, ctx.tap_ids, needs)
-    return None, [o if n else None for o, n in zip(out, needs)], None, None, None, None, None, None
+    flats = torch.ops.siglip_hip.encoder_bwd(list(grads[:2 + nt]), taps, saved, hs_rest, params, ctx.handle, ctx.image_hw,
+                                             ctx.interp, ctx.want_pooled, ctx.tap_ids, needs)
+    chunks, _ = _module_of(ctx.handle)._bucket_layout(needs)
+    pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
+    for flat, (_, _, entries) in zip(flats, chunks):
+        for i, off, n in entries:
+            pgrads[i] = flat[off:off + n].view(params[i].shape)
+    return None, pgrads, None, None, None, None, None, None
 
 
 encoder_fwd.register_autograd(_encoder_backward, setup_context=_encoder_setup_context)
@@ -554,42 +573,59 @@ class SiglipVisionModelHIP(nn.Module):
                 "SiglipVisionModelHIP: parameters changed between this forward and its backward (optimizer step, EMA "
                 "swap or load_state_dict in between re-cast the bf16 weight shadows); run backward before touching them")
 
-    def _grad_buckets(self, needs, dev):
-        """One flat fp32 bucket per group (embeddings, each block, post-LN + head) with the per-parameter gradient views
-        inside; the C side overwrites every element, so the buckets are reused from step to step (no memset, stable
-        pointers for FusedAdamW's device table) unless a parameter's .grad still aliases them (gradient accumulation,
-        zero_grad(set_to_none=False)), in which case this backward gets fresh memory."""
+    def _bucket_layout(self, needs):
+        """Pure function of (which parameters need gradients): the gradient memory plan.
+
+        Groups (embeddings, each block, post-LN + head) are listed in the order the backward completes them (head, block
+        L-1 ... first trainable block, embeddings) and cut into at most ``max_buckets`` chunks of consecutive groups; every
+        chunk is ONE flat fp32 tensor (= one DDP collective, ddp.py) holding its groups' per-parameter gradients, each
+        16-byte aligned.  Returns (chunks, groups): chunks = [(total_elems, [group names], [(param index, offset, numel)])],
+        groups = {group name: [param indices]}."""
         names = self._flat_names
         params = self._flat_params()
         groups: dict[str, list[int]] = {}
         for idx, (grp, _) in enumerate(names):
             if needs[idx]:
                 groups.setdefault(grp, []).append(idx)
+        L = self.config.num_hidden_layers
+        order = [g_ for g_ in (["head"] + [f"layer{l}" for l in range(L - 1, -1, -1)] + ["emb"]) if g_ in groups]
+        max_buckets = getattr(self._grad_reducer, "max_buckets", 8) if self._grad_reducer is not None else 8
+        per = max(1, -(-len(order) // max(1, max_buckets)))
         # q/k/v weight (and bias) gradients back to back: the C side then runs them as one dW GEMM / one column sum
         rank = {"q_w": 0, "k_w": 1, "v_w": 2, "q_b": 3, "k_b": 4, "v_b": 5}
-        grads_out = [None] * len(params)
-        buckets: dict[str, torch.Tensor] = {}
-        for grp, idxs in groups.items():
-            idxs.sort(key=lambda i: (rank.get(names[i][1], 6), i))
-            total = sum((params[i].numel() + 3) // 4 * 4 for i in idxs)   # every tensor 16-byte aligned
-            key = (grp, tuple(idxs))
+        chunks = []
+        for c0 in range(0, len(order), per):
+            members = order[c0:c0 + per]
+            off, entries = 0, []
+            for grp in members:
+                idxs = sorted(groups[grp], key=lambda i: (rank.get(names[i][1], 6), i))
+                for i in idxs:
+                    n = params[i].numel()
+                    entries.append((i, off, n))
+                    off += (n + 3) // 4 * 4
+            chunks.append((off, members, entries))
+        return chunks, groups
+
+    def _alloc_buckets(self, chunks, dev):
+        """The flat tensors of ``_bucket_layout``.  The C side overwrites every element, so they are reused from step to
+        step (no memset, stable pointers for FusedAdamW's device table) unless a parameter's .grad still aliases one
+        (gradient accumulation, zero_grad(set_to_none=False)): that backward gets fresh memory instead."""
+        params = self._flat_params()
+        flats = []
+        for ci, (total, members, entries) in enumerate(chunks):
+            key = (ci, tuple(members), tuple(e[0] for e in entries))
             flat = self._bucket_cache.get(key)
             if flat is not None and (flat.device != dev or flat.numel() != total):
                 flat = None
             if flat is not None:
                 base, end = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
-                if any(params[i].grad is not None and base <= params[i].grad.data_ptr() < end for i in idxs):
+                if any(params[i].grad is not None and base <= params[i].grad.data_ptr() < end for i, _, _ in entries):
                     flat = None
             if flat is None:
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
                 self._bucket_cache[key] = flat
-            off = 0
-            for i in idxs:
-                n = params[i].numel()
-                grads_out[i] = flat[off:off + n].view(params[i].shape)
-                off += (n + 3) // 4 * 4
-            buckets[grp] = flat
-        return grads_out, buckets, groups
+            flats.append(flat)
+        return flats
 
     def _ensure_ctx(self):
         if self._owner != id(self):      # object was copied field by field (copy.copy): do not share the original's state
@@ -676,6 +712,46 @@ class SiglipVisionModelHIP(nn.Module):
             self._shadow_key = keys
             self._shadow_serial += 1
         return self._shadow, self._weights_struct
+
+    _SHADOWED = {"q_w", "k_w", "v_w", "q_b", "k_b", "v_b", "o_w", "fc1_w", "fc1_b", "fc2_w",     # per block
+                 "patch_w", "in_proj_w", "out_proj_w", "head_fc1_w", "head_fc1_b", "head_fc2_w"}    # globals
+
+    def _unit_keys(self):
+        L = self.config.num_hidden_layers
+        keys = [[] for _ in range(L + 1)]
+        for (grp, _), p in zip(self._flat_names, self._flat_params()):
+            keys[int(grp[5:]) if grp.startswith("layer") else L].append((p.data_ptr(), p._version))
+        return [tuple(k) for k in keys]
+
+    def _units_in_sync(self):
+        """Per block (and, last entry, the globals): is the shadow arena current for the parameters as they are now?"""
+        if self._shadow is None or self._shadow_key is None:
+            return None
+        return [a == b for a, b in zip(self._unit_keys(), self._shadow_key)]
+
+    def _adopt_written_shadows(self, was_in_sync, written_ptrs):
+        """Called by ``FusedAdamW`` after a step that wrote the shadows of the parameters in ``written_ptrs`` in its own
+        pass: a unit that was in sync before the step, and whose shadowed parameters were all either written or left
+        untouched, is in sync again — adopt the new versions so the next forward does not re-cast it."""
+        if was_in_sync is None or self._shadow_key is None:
+            return
+        L = self.config.num_hidden_layers
+        now = self._unit_keys()
+        changed_ok = [True] * (L + 1)
+        pos = [0] * (L + 1)
+        for (grp, field), p in zip(self._flat_names, self._flat_params()):
+            u = int(grp[5:]) if grp.startswith("layer") else L
+            old = self._shadow_key[u][pos[u]]
+            pos[u] += 1
+            if (p.data_ptr(), p._version) != old and field in self._SHADOWED and p.data_ptr() not in written_ptrs:
+                changed_ok[u] = False
+        adopted = False
+        for u in range(L + 1):
+            if was_in_sync[u] and changed_ok[u] and now[u] != self._shadow_key[u]:
+                self._shadow_key[u] = now[u]
+                adopted = True
+        if adopted:
+            self._shadow_serial += 1
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)

@@ -52,6 +52,12 @@ class SglAdamwTensor(C.Structure):
                 ("weight_decay", C.c_float)]
 
 
+class SglAdamwAux(C.Structure):
+    _fields_ = [("dst", _fp), ("dst_t", _fp), ("dst_f32", _fp), ("ema", _fp), ("ld", C.c_int), ("ld_t", C.c_int),
+                ("rows", C.c_int), ("cols", C.c_int), ("row0", C.c_int), ("dtype", C.c_int), ("group", C.c_int),
+                ("reserved", C.c_int)]
+
+
 _lib = None
 
 
@@ -127,6 +133,11 @@ def load():
     _sig(lib, "sgl_op_grad_norm", i, [_fp, _fp, i64, f, _fp, _fp, _fp])
     _sig(lib, "sgl_op_adamw", i, [_fp, _fp, i64, C.c_double, C.c_double, C.c_double, i, _fp, _fp])
     _sig(lib, "sgl_op_ema", i, [_fp, _fp, i64, C.c_double, _fp])
+    _sig(lib, "sgl_adamw_bind_shadows", i, [C.c_void_p, C.POINTER(SglWeights), _fp, C.POINTER(SglAdamwTensor),
+                                            C.POINTER(SglAdamwAux), i])
+    _sig(lib, "sgl_op_grad_norm_scaled", i, [_fp, _fp, i64, f, f, _fp, _fp, _fp])
+    _sig(lib, "sgl_op_adamw_ex", i, [_fp, _fp, _fp, i64, C.c_double, C.c_double, C.c_double, i, _fp,
+                                     C.POINTER(C.c_float), i, C.c_double, _fp])
     _sig(lib, "sgl_op_dwconv3x3", i, [_fp, i, _fp, _fp, _fp, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_dwconv3x3_wgrad_scratch_bytes", sz, [i, i, i, i])
     _sig(lib, "sgl_op_dwconv3x3_wgrad", i, [_fp, _fp, i, _fp, i, _fp, sz, i, i, i, i, _fp])

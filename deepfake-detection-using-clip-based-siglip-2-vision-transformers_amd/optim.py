@@ -27,22 +27,54 @@ class FusedAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` semantics (decoupled weight decay, bias correction, same operation order) in one launch
     for all tensors.  ``max_grad_norm`` > 0 folds ``clip_grad_norm_(all parameters, max_grad_norm)`` into the step: the
     gradients themselves are left untouched, the clip coefficient is applied as they are read.  After ``step()``,
-    ``last_grad_norm`` is a 0-d CUDA tensor holding the pre-clip global norm (no synchronisation)."""
+    ``last_grad_norm`` is a 0-d CUDA tensor holding the pre-clip global norm (no synchronisation).
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+    In the same pass over each parameter the kernel can also write what the update invalidates (kernel work-list k11):
+
+    * ``attach_encoder(enc)``: the bf16 (or strict-fp32) weight shadows of a ``SiglipVisionModelHIP`` and their
+      transposes, so the next forward does no re-cast (the reference's autocast casts every weight every step,
+      Siglip2sidafrozen.py:1375);
+    * ``attach_ema(ema)``: ``ExponentialMovingAverage.update()`` (cifake_binary_classifier.py:222-225);
+    * ``grad_scale``: gradients are rank SUMS and this is 1/world (``GradBucketReducer(average="defer")``): folded into
+      the clip coefficient, no pass of its own.
+
+    Learning rate and weight decay travel with each launch (per parameter group), so a per-step LR scheduler does not
+    re-upload the device table."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
+                 grad_scale: float = 1.0):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) > 16:
+            raise ValueError("FusedAdamW supports at most 16 parameter groups")
         self.max_grad_norm = max_grad_norm
+        self.grad_scale = float(grad_scale)
         self.last_grad_norm = None
         self._table_key = None
+        self._aux_key = None
         self._plans = {}
         self._bufs = {}
+        self._encoders = []
+        self._ema = None
+
+    def attach_encoder(self, encoder) -> "FusedAdamW":
+        """Write ``encoder``'s weight shadows in the AdamW pass (it must own some of this optimizer's parameters)."""
+        import weakref
+        self._encoders.append(weakref.ref(encoder))
+        self._aux_key = None
+        return self
+
+    def attach_ema(self, ema) -> "FusedAdamW":
+        """Fold ``ema.update()`` into the step (``ema`` = ``ExponentialMovingAverage``; do not call update() yourself)."""
+        self._ema = ema
+        self._aux_key = None
+        return self
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _collect(self):
         ents = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if group.get("amsgrad") or group.get("maximize"):  # e.g. after load_state_dict of a torch AdamW state
                 raise RuntimeError("FusedAdamW implements plain AdamW only (amsgrad / maximize are not supported)")
             for p in group["params"]:
@@ -61,19 +93,55 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                ents.append((p, st, group))
+                ents.append((p, st, group, gi))
         return ents
 
-    def _device_table(self, lib, ents, dev):
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                     float(g["lr"]), float(g["weight_decay"])) for p, st, g in ents)
-        if key != self._table_key:
-            arr = (_lib.SglAdamwTensor * len(ents))()
-            for e, k in zip(arr, key):
-                e.p, e.g, e.m, e.v, e.n, e.lr, e.weight_decay = k
+    def _device_tables(self, lib, ents, dev):
+        """(table, aux, chunk counts): pointers only — hyper-parameters are launch arguments."""
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi)
+                    for p, st, _, gi in ents)
+        encs = [e() for e in self._encoders]
+        encs = [e for e in encs if e is not None and e._shadow is not None and e._shadow.device == dev]
+        ema_ptrs = ()
+        if self._ema is not None:
+            by_param = {id(p): self._ema.shadow[n] for n, p in self._ema.model.named_parameters()
+                        if n in self._ema.shadow}
+            ema_ptrs = tuple(by_param[id(p)].data_ptr() if id(p) in by_param else 0 for p, _, _, _ in ents)
+        aux_key = (key, tuple((id(e), e._shadow.data_ptr(), id(e._weights_struct)) for e in encs), ema_ptrs)
+        if key != self._table_key or aux_key != self._aux_key:
+            n = len(ents)
+            arr = (_lib.SglAdamwTensor * n)()
+            aux = (_lib.SglAdamwAux * n)()
+            for i, (e, k) in enumerate(zip(arr, key)):
+                e.p, e.g, e.m, e.v, e.n = k[:5]
+                e.lr, e.weight_decay = 0.0, 0.0
+                aux[i].group = k[5]
+                if ema_ptrs and ema_ptrs[i]:
+                    sh = by_param[id(ents[i][0])]
+                    if sh.dtype != torch.float32 or sh.stride() != ents[i][0].stride():
+                        raise RuntimeError("EMA shadows must be fp32 with the parameter's layout")
+                    aux[i].ema = ema_ptrs[i]
+            bound = set()
+            for enc in encs:
+                # only row-major masters can be tiled (channels_last patch weights keep the encoder's own re-cast)
+                lib.sgl_adamw_bind_shadows(enc._ctx, C.byref(enc._weights_struct), enc._shadow.data_ptr(), arr, aux, n)
+            chunks = []
+            for i, (p, _, _, _) in enumerate(ents):
+                if (aux[i].dst or aux[i].dst_t) and not p.is_contiguous():
+                    aux[i].dst = aux[i].dst_t = None
+                if aux[i].dst or aux[i].dst_t:
+                    chunks.append(((aux[i].rows + 63) // 64) * ((aux[i].cols + 63) // 64) * 4096)
+                    bound.add(p.data_ptr())
+                else:
+                    chunks.append(p.numel())
+                    if aux[i].dst_f32:
+                        bound.add(p.data_ptr())
             self._bufs["table"] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            self._table_key = key
-        return self._bufs["table"]
+            self._bufs["aux"] = torch.frombuffer(bytearray(bytes(aux)), dtype=torch.uint8).to(dev)
+            self._bufs["chunks"] = tuple(chunks)
+            self._bufs["bound"] = bound
+            self._table_key, self._aux_key = key, aux_key
+        return self._bufs["table"], self._bufs["aux"], self._bufs["chunks"], encs
 
     def _plan(self, lib, numel, members, dev):
         """Block map over the tensors listed in ``members`` (indices into the table), cached."""
@@ -103,37 +171,47 @@ class FusedAdamW(torch.optim.Optimizer):
             return loss
         lib = _lib.load()
         dev = ents[0][0].device
-        if any(p.device != dev for p, _, _ in ents):
+        if any(p.device != dev for p, _, _, _ in ents):
             raise RuntimeError("FusedAdamW: all parameters must live on one device")
-        table = self._device_table(lib, ents, dev)
-        numel = tuple(p.numel() for p, _, _ in ents)
+        table, aux, chunks, encs = self._device_tables(lib, ents, dev)
+        numel = tuple(p.numel() for p, _, _, _ in ents)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        in_sync = [enc._units_in_sync() for enc in encs]
         # one AdamW launch per distinct (betas, eps, step): a single one for every trainer of the reference (one param
         # group, every trainable tensor receives a gradient every step); torch tracks the step per tensor, so do we
         launches = {}
-        for i, (_, st, g) in enumerate(ents):
+        for i, (_, st, g, _) in enumerate(ents):
             launches.setdefault((g["betas"][0], g["betas"][1], g["eps"], int(st["step"].item())), []).append(i)
+        hyper = (C.c_float * (2 * len(self.param_groups)))()
+        for gi, g in enumerate(self.param_groups):
+            hyper[2 * gi], hyper[2 * gi + 1] = float(g["lr"]), float(g["weight_decay"])
         norm_ptr = None
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         with torch.cuda.device(dev):
-            if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            if clip or self.grad_scale != 1.0:
                 bmap, nb = self._plan(lib, numel, tuple(range(len(ents))), dev)
                 if "norm" not in self._bufs or self._bufs["partials"].numel() < max(nb, 1):
                     self._bufs["partials"] = torch.empty(max(nb, 1), device=dev, dtype=torch.float32)
                     self._bufs["norm"] = torch.zeros(2, device=dev, dtype=torch.float32)
-                _lib.check(lib.sgl_op_grad_norm(table.data_ptr(), bmap.data_ptr(), nb, float(self.max_grad_norm),
-                                                self._bufs["partials"].data_ptr(), self._bufs["norm"].data_ptr(),
-                                                stream), "sgl_op_grad_norm")
+                _lib.check(lib.sgl_op_grad_norm_scaled(table.data_ptr(), bmap.data_ptr(), nb,
+                                                       float(self.max_grad_norm) if clip else 0.0, self.grad_scale,
+                                                       self._bufs["partials"].data_ptr(), self._bufs["norm"].data_ptr(),
+                                                       stream), "sgl_op_grad_norm_scaled")
                 norm_ptr = self._bufs["norm"].data_ptr()
                 self.last_grad_norm = self._bufs["norm"][0]
+            decay = float(self._ema.decay) if self._ema is not None else 0.0
             for (beta1, beta2, eps, step0), members in launches.items():
-                bmap, nb = self._plan(lib, numel, tuple(members), dev)
-                _lib.check(lib.sgl_op_adamw(table.data_ptr(), bmap.data_ptr(), nb, float(beta1), float(beta2),
-                                            float(eps), step0 + 1, norm_ptr, stream), "sgl_op_adamw")
-        for _, st, _ in ents:
+                bmap, nb = self._plan(lib, chunks, tuple(members), dev)
+                _lib.check(lib.sgl_op_adamw_ex(table.data_ptr(), aux.data_ptr(), bmap.data_ptr(), nb, float(beta1),
+                                               float(beta2), float(eps), step0 + 1, norm_ptr, hyper,
+                                               len(self.param_groups), decay, stream), "sgl_op_adamw_ex")
+        for _, st, _, _ in ents:
             st["step"] += 1
         # the kernel wrote the parameters behind autograd's back: bump their version counters, which is what everything
         # that caches on `p._version` keys on (the encoder's bf16 weight shadows, saved-tensor checks)
-        torch.autograd.graph.increment_version([p for p, _, _ in ents])
+        torch.autograd.graph.increment_version([p for p, _, _, _ in ents])
+        for enc, ok in zip(encs, in_sync):
+            enc._adopt_written_shadows(ok, self._bufs["bound"])
         return loss
 
 
@@ -165,30 +243,39 @@ def global_grad_norm(parameters) -> torch.Tensor:
 
 
 class ExponentialMovingAverage:
-    """The CiFake trainer's weight EMA (cifake_binary_classifier.py:211-236) with ``update()`` as ONE HIP launch over
-    all trainable tensors instead of three elementwise kernels per tensor.  Same attributes and methods: ``shadow``
-    (name -> tensor, what the reference stores as ``checkpoint['ema_state_dict']``), ``update()``, ``apply_shadow()``,
-    ``restore()``."""
+    """Weight EMA with the surface of the CiFake trainer's helper (cifake_binary_classifier.py:211-236: ``shadow`` — what
+    it stores as ``checkpoint['ema_state_dict']`` — ``update()``, ``apply_shadow()``, ``restore()``), laid out for the GPU:
+    all averages live in ONE flat fp32 buffer (``shadow[name]`` are views into it), ``update()`` is one HIP launch over
+    every trainable tensor (12 B/parameter) or, after ``FusedAdamW.attach_ema(self)``, no launch at all (the AdamW kernel
+    updates the average while the new parameter is still in registers), and the eval-time swap exchanges storage
+    pointers instead of copying weights."""
 
     def __init__(self, model, decay=0.9999):
         self.model = model
         self.decay = decay
-        self.shadow = {}
-        self.backup = {}
-        for name, param in model.named_parameters():
-            if param.requires_grad:
-                self.shadow[name] = param.data.clone()
+        tracked = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in tracked]          # 16-byte aligned slots
+        dev = tracked[0][1].device if tracked else "cpu"
+        self._flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self.shadow, off = {}, 0
+        for (n, p), sz in zip(tracked, sizes):
+            view = torch.as_strided(self._flat, p.shape, p.stride(), off) if _is_dense(p) else \
+                self._flat[off:off + p.numel()].view(p.shape)
+            view.copy_(p.detach())
+            self.shadow[n] = view
+            off += sz
+        self._live = None      # name -> the training weights' storage while the averages are swapped in
         self._key = None
         self._bufs = None
 
     def _plan(self, lib):
-        ents = [(p, self.shadow[n]) for n, p in self.model.named_parameters() if p.requires_grad]
+        ents = [(p, self.shadow[n]) for n, p in self.model.named_parameters() if n in self.shadow]
         key = tuple((p.data_ptr(), s.data_ptr(), p.numel()) for p, s in ents)
         if key != self._key:
             for p, s in ents:
-                if not (p.is_cuda and s.is_cuda and p.dtype == torch.float32 and s.dtype == torch.float32
-                        and _is_dense(p) and s.stride() == p.stride()):
-                    raise RuntimeError("ExponentialMovingAverage handles contiguous fp32 CUDA parameters only")
+                if not (p.is_cuda and s.is_cuda and p.dtype == torch.float32 and _is_dense(p)
+                        and s.stride() == p.stride()):
+                    raise RuntimeError("ExponentialMovingAverage handles dense fp32 CUDA parameters only")
             dev = ents[0][0].device
             arr = (_lib.SglAdamwTensor * len(ents))()
             for e, (pp, sp, n) in zip(arr, key):
@@ -204,6 +291,7 @@ class ExponentialMovingAverage:
 
     @torch.no_grad()
     def update(self):
+        """average <- average*decay + weight*(1-decay) for every tracked tensor, one launch."""
         if not self.shadow:
             return
         lib = _lib.load()
@@ -213,12 +301,19 @@ class ExponentialMovingAverage:
                                       torch.cuda.current_stream(dev).cuda_stream), "sgl_op_ema")
 
     def apply_shadow(self):
-        for name, param in self.model.named_parameters():
-            if param.requires_grad:
-                self.backup[name] = param.data.clone()
-                param.data = self.shadow[name]
+        """Evaluate with the averaged weights: every tracked parameter points at its average until ``restore()``."""
+        if self._live is not None:
+            raise RuntimeError("apply_shadow() called twice without restore()")
+        self._live = {}
+        for n, p in self.model.named_parameters():
+            if n in self.shadow:
+                self._live[n] = p.data
+                p.data = self.shadow[n]
 
     def restore(self):
-        for name, param in self.model.named_parameters():
-            if param.requires_grad:
-                param.data = self.backup[name]
+        if self._live is None:
+            return
+        for n, p in self.model.named_parameters():
+            if n in self._live:
+                p.data = self._live[n]
+        self._live = None

@@ -248,6 +248,38 @@ int sgl_op_grad_norm(const sgl_adamw_tensor* table, const int32_t* blockmap, int
  * step >= 1 is the bias-correction exponent; norm_and_coef (may be NULL) is the output of sgl_op_grad_norm. */
 int sgl_op_adamw(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double beta1, double beta2,
                  double eps, int step, const float* norm_and_coef, sgl_stream stream);
+/* ---- AdamW that also leaves behind everything a parameter update invalidates (kernel work-list k11) -----------------
+ * Per table entry, optional destinations written in the same pass as the update:
+ *   dst / dst_t : compute-dtype (dtype) row-major copy dst[(r-row0)*ld + c] and transposed copy dst_t[c*ld_t + (r-row0)]
+ *                 of the rows r >= row0 of the [rows, cols] parameter: the encoder's weight shadows (sgl_prepare_weights
+ *                 layouts; pad regions are never touched), so no re-cast is needed before the next forward;
+ *   dst_f32     : fp32 copy of a 1-D tensor (the fused qkv / fc1 bias vectors of the shadow arena);
+ *   ema         : ExponentialMovingAverage shadow (cifake_binary_classifier.py:222-225): ema = ema*decay + p*(1-decay);
+ *   group       : index into the per-launch (lr, weight_decay) list (changing the learning rate every step then needs no
+ *                 table upload); -1 = use the table entry's own lr / weight_decay.
+ * Entries with dst or dst_t are walked in 64x64 tiles: plan them as ceil(rows/64)*ceil(cols/64) chunks, i.e. pass
+ * that count * 4096 as the tensor's numel to sgl_adamw_plan. */
+typedef struct {
+  void* dst;
+  void* dst_t;
+  float* dst_f32;
+  float* ema;
+  int ld, ld_t, rows, cols, row0, dtype, group, reserved;
+} sgl_adamw_aux;
+/* HOST helper: fills aux[i].{dst, dst_t, dst_f32, ld, ld_t, rows, cols, row0, dtype} for every table entry whose .p is one
+ * of the master tensors in `w` that has a copy in the shadow arena `shadow` of `ctx` (table and aux are HOST arrays of
+ * ntensors entries; other aux fields are left untouched).  Returns the number of entries bound. */
+int sgl_adamw_bind_shadows(const sgl_ctx* ctx, const sgl_weights* w, void* shadow, const sgl_adamw_tensor* table_host,
+                           sgl_adamw_aux* aux_host, int ntensors);
+/* sgl_op_grad_norm with a gradient scale s (gradients are rank sums, s = 1/world): [0] = s*norm,
+ * [1] = s*min(1, max_norm/(s*norm + 1e-6)) (= s when max_norm <= 0). */
+int sgl_op_grad_norm_scaled(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, float max_norm,
+                            float grad_scale, float* partials, float* norm_and_coef, sgl_stream stream);
+/* group_lr_wd_host: HOST array of ngroups (<= 16) {lr, weight_decay} pairs passed by value with the launch, or NULL with
+ * ngroups = 0; ema_decay is used by entries with aux.ema != NULL. */
+int sgl_op_adamw_ex(const sgl_adamw_tensor* table, const sgl_adamw_aux* aux, const int32_t* blockmap, int64_t nblocks,
+                    double beta1, double beta2, double eps, int step, const float* norm_and_coef,
+                    const float* group_lr_wd_host, int ngroups, double ema_decay, sgl_stream stream);
 /* Weight EMA of the CiFake trainer (ExponentialMovingAverage.update, cifake_binary_classifier.py:222-225):
  * shadow = shadow*decay + p*(1-decay) for every table entry, with p = entry.p (read only) and shadow = entry.m. */
 int sgl_op_ema(const sgl_adamw_tensor* table, const int32_t* blockmap, int64_t nblocks, double decay,

@@ -54,7 +54,29 @@ def _worker(rank, world, port, q):
         ws = [torch.zeros_like(m.weight) for _ in range(world)]
         dist.all_gather(ws, m.weight.data)
         ok_bcast = torch.equal(ws[0], ws[1])
-        q.put((rank, ok_buckets, ok_head, ok_bcast, pkg.ddp.shard_batch(11, rank, world)))
+        # bf16 wire with fp32 accumulation (all-to-all of shards + all-gather), deferred averaging, no_sync, async heads
+        red2 = pkg.GradBucketReducer(wire="bf16", average="defer")
+        b2 = [torch.randn(1001), torch.randn(64)]
+        l2 = [b.clone() for b in b2]
+        with red2.no_sync():
+            red2.reduce_bucket(b2[0])
+            red2.finish()
+        ok_nosync = torch.equal(b2[0], l2[0]) and red2.collectives_issued == 0
+        for b in b2:
+            red2.reduce_bucket(b)
+        lin2 = torch.nn.Linear(4, 2)
+        lin2.weight.grad = torch.full_like(lin2.weight, float(rank + 1))
+        lin2.bias.grad = torch.full_like(lin2.bias, 1.0)
+        red2.reduce_grads(lin2.parameters(), async_op=True)
+        red2.finish()
+        ok_wire = red2.grad_scale == 0.5 and red2.collectives_issued == 3
+        for b, lb in zip(b2, l2):
+            allb = [torch.zeros_like(lb) for _ in range(world)]
+            dist.all_gather(allb, lb)
+            want = torch.stack([a.bfloat16().float() for a in allb]).sum(0)      # SUM (average deferred), bf16 inputs
+            ok_wire = ok_wire and torch.allclose(b, want.bfloat16().float(), atol=1e-6)
+        ok_wire = ok_wire and torch.allclose(lin2.weight.grad, torch.full_like(lin2.weight, 3.0))
+        q.put((rank, ok_buckets, ok_head and ok_nosync and ok_wire, ok_bcast, pkg.ddp.shard_batch(11, rank, world)))
     finally:
         dist.destroy_process_group()
 
@@ -150,3 +172,96 @@ def test_encoder_backward_all_reduces_every_bucket_world2():
         assert p.exitcode == 0
     for rank, worst in res:
         assert worst < 2e-5, f"rank {rank}: averaged gradients differ from the single-process mean by {worst}"
+
+
+def _sid_worker(rank, world, port, q):
+    """Frozen-prefix SID multi-task model (Siglip2sidafrozen.py:750-803): encoder gradient chunks exchanged from inside
+    the backward, decoder / classifier gradients through the asynchronous reduce_grads, 1/world folded into FusedAdamW's
+    clip coefficient (average='defer'), two optimizer steps; every rank must end with identical parameters, equal to a
+    single-process run over the concatenated batch."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H = pkg.heads
+        cfg = pkg.get_config("hostile")
+
+        def make():
+            enc = pkg.SiglipVisionModelHIP(cfg, compute_dtype="fp32")
+            enc.load_state_dict(pkg.weights.seeded_state_dict(cfg, 4))
+            torch.manual_seed(0)
+            return H.SigLIP2MTL(enc, seg_layers=(0, 1, -1), embed_dim=32, freeze_below=1).cuda()
+
+        xs = [pkg.weights.seeded_pixels(2, 42, 42, seed=70 + r).cuda() for r in range(world)]
+        ys = [torch.tensor([r, 2 - r]).cuda() for r in range(world)]
+        ms = [(pkg.weights.seeded_tensor(f"mask{r}", (2, 1, 42, 42), 1.0) > 0.1).float().cuda() for r in range(world)]
+        has = torch.tensor([True, True]).cuda()
+
+        def loss_of(model, r):
+            cls, seg = model(xs[r])
+            return H.mtl_loss(cls, seg, ys[r], ms[r], has)
+
+        # distributed run: this rank sees only its shard
+        model = make()
+        pkg.ddp.broadcast_parameters(model, src=0)
+        red = pkg.GradBucketReducer(average="defer", max_buckets=2).attach(model.encoder)
+        heads = [p for n, p in model.named_parameters() if not n.startswith("encoder.") and p.requires_grad]
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        opt = pkg.FusedAdamW(trainable, lr=2e-3, weight_decay=0.01, max_grad_norm=0.5, grad_scale=red.grad_scale)
+        opt.attach_encoder(model.encoder)
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss_of(model, rank).backward()
+            red.reduce_grads(heads, async_op=True)
+            red.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        n_coll = red.collectives_issued
+        mine = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+
+        # single-process reference over both shards (mean of the per-rank losses = what averaging gradients computes)
+        ref = make()
+        ropt = pkg.FusedAdamW([p for p in ref.parameters() if p.requires_grad], lr=2e-3, weight_decay=0.01,
+                              max_grad_norm=0.5)
+        for _ in range(2):
+            ropt.zero_grad(set_to_none=True)
+            (sum(loss_of(ref, r) for r in range(world)) / world).backward()
+            ropt.step()
+        torch.cuda.synchronize()
+        worst, who = 0.0, None
+        for n, p in ref.named_parameters():
+            d = (mine[n] - p.detach().cpu()).abs().max().item() / (p.detach().abs().max().item() + 1e-12)
+            if d > worst:
+                worst, who = d, n
+        # identical across ranks, bit for bit
+        flat = torch.cat([v.reshape(-1) for v in mine.values()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        q.put((rank, worst, who, bool(torch.equal(both[0], both[1])), n_coll))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sid_frozen_prefix_two_ranks_identical_parameters_after_two_steps():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, worst, who, same, n_coll in res:
+        assert same, "ranks ended with different parameters"
+        assert worst < 5e-5, f"rank {rank}: {who} differs from the single-process run by {worst}"
+        # per step: 2 encoder chunks (max_buckets=2: head+block 1) + 1 flat message for decoder/cls head
+        assert n_coll == 2 * 3, n_coll

@@ -143,3 +143,62 @@ def test_ema_matches_reference_formula_and_swaps_weights():
     ema.restore()
     for n, p in model.named_parameters():
         assert torch.equal(p, live[n])
+
+
+def test_step_writes_encoder_shadows_ema_and_folds_grad_scale():
+    """Kernel work-list k11: FusedAdamW with an attached encoder writes the bf16 weight shadows (and their transposes) in
+    the AdamW pass, so the next forward re-casts nothing; attach_ema folds the EMA in; grad_scale folds 1/world in; a
+    changed learning rate needs no table upload.  Checked against torch.optim.AdamW + explicit formulas."""
+    pkg = entry.load_package()
+    for cfg_name, mode in (("hostile", "bf16"), ("tiny", "fp32")):
+        cfg = pkg.get_config(cfg_name)
+        sd = pkg.weights.seeded_state_dict(cfg, seed=3)
+        res = cfg.image_size
+        x = pkg.weights.seeded_pixels(2, res, res, seed=4).cuda()
+
+        def make():
+            m = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
+            m.load_state_dict(sd)
+            return m.cuda()
+        fused, plain = make(), make()
+        opt_f = pkg.FusedAdamW(fused.parameters(), lr=1e-3, weight_decay=0.05, max_grad_norm=0.7, grad_scale=0.5)
+        opt_f.attach_encoder(fused)
+        ema = pkg.ExponentialMovingAverage(fused, decay=0.9)
+        opt_f.attach_ema(ema)
+        opt_p = pkg.FusedAdamW(plain.parameters(), lr=1e-3, weight_decay=0.05, max_grad_norm=0.7)
+        ema_ref = {n: p.detach().clone() for n, p in fused.named_parameters()}
+        for step in range(3):
+            for m, opt in ((fused, opt_f), (plain, opt_p)):
+                out = m(pixel_values=x)
+                loss = out.pooler_output.square().mean() + out.last_hidden_state.mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+            with torch.no_grad():            # fused holds rank SUMS of a 2-rank job: twice the mean gradient
+                for p in fused.parameters():
+                    p.grad.mul_(2.0)
+            if step == 2:                    # an LR scheduler step: hyper-parameters are launch arguments
+                for opt in (opt_f, opt_p):
+                    opt.param_groups[0]["lr"] = 5e-4
+                key_before = opt_f._table_key
+            serial = fused._shadow_serial
+            opt_f.step()
+            opt_p.step()
+            if step == 2:
+                assert opt_f._table_key is key_before
+            assert all(fused._units_in_sync()), "every block's shadows were written by the optimizer"
+            assert fused._shadow_serial == serial + 1
+            assert not any(plain._units_in_sync()[:-1]), "without attach_encoder the next forward must re-cast"
+            for (n, a), (_, b) in zip(fused.named_parameters(), plain.named_parameters()):
+                torch.testing.assert_close(a.detach(), b.detach(), rtol=3e-6, atol=1e-7, msg=lambda s_: f"{n}: {s_}")
+                ema_ref[n] = ema_ref[n] * 0.9 + a.detach() * 0.1
+                torch.testing.assert_close(ema.shadow[n], ema_ref[n], rtol=3e-6, atol=1e-7)
+            # the shadows the optimizer wrote give the same forward as a from-scratch re-cast of the same parameters
+            with torch.no_grad():
+                o_f = fused(pixel_values=x).pooler_output
+                assert fused._shadow_serial == serial + 1, "the forward after the step must not have re-cast anything"
+                o_p = plain(pixel_values=x).pooler_output
+            assert torch.allclose(o_f, o_p, rtol=0, atol=2e-5), (o_f - o_p).abs().max()
+        # a parameter changed behind the optimizer's back is not adopted: the encoder re-casts that block itself
+        with torch.no_grad():
+            fused.encoder.layers[0].mlp.fc1.weight.mul_(1.01)
+        assert fused._units_in_sync()[0] is False
