@@ -318,6 +318,9 @@ hipError_t gemm_nt2_bf16(const void* A, int lda, const void* B, int ldb, int M, 
                          const EpiParams& p, hipStream_t s);
 hipError_t gemm_tn2_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int m_per,
                          int splits, const EpiParams& p, hipStream_t s);
+// persistent generation 7 (gemm_bf16_v3.hip); hipErrorNotSupported = outside its envelope, fall back to generation 6
+hipError_t gemm_nt7_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, int out_dtype,
+                         const EpiParams& p, hipStream_t s);
 // SGL_GEMM_GEN=1 forces the 128x128 register-staged kernels (A/B comparisons)
 static int gemm_generation() {
   static int gen = -1;
@@ -350,8 +353,16 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if ((lda % 8) || (ldb % 8) || (K % 8) || K <= 0) return hipErrorInvalidValue;
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
-  if (gemm_generation() != 1 && M >= 2048 && N >= 256)
+  if (gemm_generation() != 1 && M >= 2048 && N >= 256) {
+    // generation 7 (persistent tile loop, gemm_bf16_v3.hip) is opt-in: measured equal-or-slower than generation 6 on
+    // the encoder's shapes (negative results) — kept for A/B runs: SGL_GEMM_GEN=7
+    static const bool gen7 = getenv("SGL_GEMM_GEN") && atoi(getenv("SGL_GEMM_GEN")) == 7;
+    if (gen7) {
+      const hipError_t e = gemm_nt7_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
+      if (e != hipErrorNotSupported) return e;
+    }
     return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
+  }
   const bf16* A = (const bf16*)A_;
   const bf16* B = (const bf16*)B_;
 #define SGL_CASE(E)                                                                   \

@@ -167,6 +167,24 @@ __device__ __forceinline__ void tile_of_unit(int u, int tiles_m, int tiles_n, in
   tile_m = band * bh + (r - tile_n * rows);
 }
 
+// "B-stationary" alternative (band_h < 0 selects it, column-group width = -band_h): XCD x owns the contiguous range of row
+// tiles [x*tiles_m/8, (x+1)*tiles_m/8) and walks it once per group of `cgw` column tiles — column group outermost, then
+// rows, then the group's columns.  The ~32 workgroups an XCD runs at once are then (32/cgw) rows x cgw columns, and the
+// NEXT 32 reuse the same cgw weight panels (4 x 590 KB at K = 1152: they stay in the XCD's 4-MiB L2) while only the
+// activation panels stream: per 32 tiles 8 panel fetches instead of 12.  blockIdx b -> (XCD b & 7, local index b >> 3).
+__device__ __forceinline__ bool tile_of_local(int xcd, int v, int tiles_m, int tiles_n, int cgw, int& tm, int& tn) {
+  const int r_lo = (xcd * tiles_m) >> 3, r_hi = ((xcd + 1) * tiles_m) >> 3;
+  const int R = r_hi - r_lo;
+  if (v >= R * tiles_n) return false;
+  const int full = R * cgw;
+  const int g = v / full, rem = v - g * full;
+  const int w = (tiles_n - g * cgw < cgw) ? tiles_n - g * cgw : cgw;
+  const int r = rem / w;
+  tm = r_lo + r;
+  tn = g * cgw + (rem - r * w);
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------------
 template <int EPI, typename TOut>
 __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict__ A, int lda,
@@ -311,10 +329,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict
                                                           int tiles_m, int tiles_n, int band_h, EpiParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntiles = tiles_m * tiles_n;
-  const int unit = unit_of_block(blockIdx.x, (ntiles + 7) >> 3);
-  if (unit >= ntiles) return;  // whole block exits together
   int tile_m, tile_n;
-  tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n, band_h);
+  if (band_h < 0) {
+    if (!tile_of_local(blockIdx.x & 7, blockIdx.x >> 3, tiles_m, tiles_n, -band_h, tile_m, tile_n)) return;
+  } else {
+    const int unit = unit_of_block(blockIdx.x, (ntiles + 7) >> 3);
+    if (unit >= ntiles) return;  // whole block exits together
+    tile_of_unit(unit, tiles_m, tiles_n, tile_m, tile_n, band_h);
+  }
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = (w >> 1) & 1, wc = (w & 1) + 2 * (w >> 2), grp = w >> 2;
@@ -419,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict
   }
   if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
+  if (p.atomic == 77) return;   // developer experiment (SGL_NT6_SKIP_EPI): main loop only
   store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
 }
 
@@ -649,10 +672,15 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
     }
     // band height of the grouped tile order: 8 row-tiles for wide outputs, 4 when there are few column tiles (measured
     // on one box: qkv N=3456 +3 %, fc2 N=1152 +1.5 % with 4; fc1 N=4352 best with 8).  SGL_BAND overrides.
-    static const int band_env = getenv("SGL_BAND") ? atoi(getenv("SGL_BAND")) : 0;
-    const int band_h = band_env > 0 ? band_env : (tiles_n >= 16 ? 8 : 4);
-    hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
-                       tiles_m, tiles_n, band_h, p);
+    static const int band_env = getenv("SGL_BAND") ? atoi(getenv("SGL_BAND")) : 0;   // < 0: B-stationary, cgw = -value
+    const int band_h = band_env != 0 ? band_env : (tiles_n >= 16 ? 8 : 4);
+    int grid6 = grid;
+    if (band_h < 0) grid6 = 8 * (((tiles_m + 7) / 8) * tiles_n);   // 8 XCDs x the largest per-XCD tile count
+    static const bool skip_epi = getenv("SGL_NT6_SKIP_EPI") != nullptr;
+    EpiParams pp = p;
+    if (skip_epi && EPI != EPI_F32) pp.atomic = 77;
+    hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid6), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
+                       tiles_m, tiles_n, band_h, pp);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,

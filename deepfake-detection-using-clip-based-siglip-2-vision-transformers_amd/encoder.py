@@ -353,7 +353,8 @@ def _encoder_backward(ctx, grads):
     for flat, (_, _, entries) in zip(flats, chunks):
         for i, off, n in entries:
             pgrads[i] = flat[off:off + n].view(params[i].shape)
-    return None, pgrads, None, None, None, None, None, None
+    # pytree structure of the inputs: an EMPTY int list is a list node, a non-empty one a leaf (torch/_library/autograd.py)
+    return None, pgrads, None, None, None, None, ([] if len(ctx.tap_ids) == 0 else None), None
 
 
 encoder_fwd.register_autograd(_encoder_backward, setup_context=_encoder_setup_context)
@@ -537,6 +538,7 @@ class SiglipVisionModelHIP(nn.Module):
         self._ws_cache = None
         self._bucket_cache = {}
         self._pending_fwd = {}
+        self._fwd_count = 0
         self._owner = id(self)
         self._handle = _NEXT_HANDLE[0]
         _NEXT_HANDLE[0] += 1
@@ -565,6 +567,7 @@ class SiglipVisionModelHIP(nn.Module):
         if len(self._pending_fwd) > 64:
             self._pending_fwd.clear()
         self._pending_fwd[saved.data_ptr()] = self._shadow_serial
+        self._fwd_count += 1
 
     def _check_backward(self, saved):
         serial = self._pending_fwd.get(saved.data_ptr())
@@ -608,22 +611,26 @@ class SiglipVisionModelHIP(nn.Module):
 
     def _alloc_buckets(self, chunks, dev):
         """The flat tensors of ``_bucket_layout``.  The C side overwrites every element, so they are reused from step to
-        step (no memset, stable pointers for FusedAdamW's device table) unless a parameter's .grad still aliases one
-        (gradient accumulation, zero_grad(set_to_none=False)): that backward gets fresh memory instead."""
+        step (no memset, stable pointers for FusedAdamW's device table) — but only when that is provably safe: no
+        parameter's .grad still aliases the cached tensor (gradient accumulation, zero_grad(set_to_none=False)) AND a
+        training forward has run since the backward that last filled it (two backward invocations of this module inside
+        ONE autograd pass — siamese use, a loss summed over two forward calls — must not share memory: the first one's
+        gradients may not have been accumulated yet).  Otherwise this backward gets fresh memory."""
         params = self._flat_params()
         flats = []
         for ci, (total, members, entries) in enumerate(chunks):
             key = (ci, tuple(members), tuple(e[0] for e in entries))
-            flat = self._bucket_cache.get(key)
-            if flat is not None and (flat.device != dev or flat.numel() != total):
-                flat = None
-            if flat is not None:
+            hit = self._bucket_cache.get(key)
+            flat = None
+            if hit is not None and hit[0].device == dev and hit[0].numel() == total and hit[1] != self._fwd_count:
+                flat = hit[0]
                 base, end = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
                 if any(params[i].grad is not None and base <= params[i].grad.data_ptr() < end for i, _, _ in entries):
                     flat = None
             if flat is None:
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
-                self._bucket_cache[key] = flat
+            if hit is None or hit[1] != self._fwd_count:
+                self._bucket_cache[key] = (flat, self._fwd_count)
             flats.append(flat)
         return flats
 

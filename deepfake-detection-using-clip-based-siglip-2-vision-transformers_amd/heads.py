@@ -206,6 +206,103 @@ class _DepthwiseConv3x3Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _GateMulFn(torch.autograd.Function):
+    """y = sigmoid(g) * x in one HBM pass (csrc/decoder_tail.hip), backward (dg w.r.t. the PRE-sigmoid gate, dx) in one
+    more: the SE-style gate of the SID decoder (`gate * x`, Siglip2sidafrozen.py:741-742) on (B*N, E*K) activations."""
+
+    @staticmethod
+    def forward(ctx, g, x):
+        from . import lib as _lib
+        lib = _lib.load()
+        dt = g.dtype if g.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        g2, x2 = g.to(dt).contiguous(), x.to(dt).contiguous()
+        y = torch.empty_like(x2)
+        code = _lib.SGL_DTYPE_BF16 if dt == torch.bfloat16 else _lib.SGL_DTYPE_F32
+        _lib.check(lib.sgl_op_gate_mul(g2.data_ptr(), x2.data_ptr(), y.data_ptr(), g2.numel(), code,
+                                       _lib.current_stream_handle()), "sgl_op_gate_mul")
+        ctx.save_for_backward(g2, x2)
+        ctx.code, ctx.gdt, ctx.xdt = code, g.dtype, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import lib as _lib
+        lib = _lib.load()
+        g2, x2 = ctx.saved_tensors
+        dy2 = dy.to(g2.dtype).contiguous()
+        dg = torch.empty_like(g2) if ctx.needs_input_grad[0] else None
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.sgl_op_gate_mul_bwd(dy2.data_ptr(), g2.data_ptr(), x2.data_ptr(), _lib.ptr(dg), _lib.ptr(dx),
+                                           g2.numel(), ctx.code, _lib.current_stream_handle()), "sgl_op_gate_mul_bwd")
+        return (None if dg is None else dg.to(ctx.gdt)), (None if dx is None else dx.to(ctx.xdt))
+
+
+@torch.compiler.disable
+def _gate_mul(gate_pre: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    nv = 8 if gate_pre.dtype == torch.bfloat16 else 4
+    if gate_pre.is_cuda and gate_pre.shape == x.shape and gate_pre.numel() % nv == 0 and gate_pre.numel() >= 4096:
+        return _GateMulFn.apply(gate_pre, x)
+    return torch.sigmoid(gate_pre) * x
+
+
+class _SegLossFromLowresFn(torch.autograd.Function):
+    """`bce_dice_loss(F.interpolate(logit_lr, (S,S), 'bilinear'), masks)` over the images flagged in `sel`, without
+    ever forming the (B,1,S,S) logits: csrc/decoder_tail.hip evaluates every output pixel from its four low-res logits in
+    registers (forward: per-image partial sums; backward: transposed interpolation gathered per low-res pixel, fixed order).
+    No host synchronisation: an empty selection gives 0 (the reference skips the term, Siglip2sidafrozen.py:1380-1389)."""
+
+    @staticmethod
+    def forward(ctx, logit_lr, masks, sel, bce_w, dice_w, eps):
+        from . import lib as _lib
+        lib = _lib.load()
+        B, g = logit_lr.shape[0], logit_lr.shape[-1]
+        S = masks.shape[-1]
+        lr = logit_lr.detach().reshape(B, g, g).float().contiguous()
+        t = masks.reshape(B, S, S).float().contiguous()
+        chunks = lib.sgl_op_seg_loss_chunks(S)
+        partial = torch.empty(B, chunks, 4, device=lr.device, dtype=torch.float32)
+        _lib.check(lib.sgl_op_seg_loss_fwd(lr.data_ptr(), t.data_ptr(), partial.data_ptr(), B, g, S,
+                                           _lib.current_stream_handle()), "sgl_op_seg_loss_fwd")
+        sums = partial.sum(1)                                   # (B, 4), fixed order
+        w = sel.to(torch.float32)
+        n = w.sum()
+        nz = (n > 0).to(torch.float32)
+        n1 = n.clamp(min=1.0)
+        bce = (sums[:, 0] * w).sum() / (n1 * float(S * S))
+        dice_b = 2.0 * sums[:, 1] / (sums[:, 2] + sums[:, 3] + eps)
+        dice = 1.0 - (dice_b * w).sum() / n1
+        loss = (bce_w * bce + dice_w * dice) * nz
+        ctx.save_for_backward(lr, t, sums, w, n1, nz)
+        ctx.cfg = (B, g, S, bce_w, dice_w, eps, logit_lr.shape, logit_lr.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import lib as _lib
+        lib = _lib.load()
+        lr, t, sums, w, n1, nz = ctx.saved_tensors
+        B, g, S, bce_w, dice_w, eps, shape, dtype = ctx.cfg
+        up = dloss.float() * nz
+        coef = torch.stack([up * bce_w * w / (n1 * float(S * S)), -up * dice_w * w / n1], dim=1).contiguous()
+        dlr = torch.empty_like(lr)
+        _lib.check(lib.sgl_op_seg_loss_bwd(lr.data_ptr(), t.data_ptr(), sums.contiguous().data_ptr(), coef.data_ptr(),
+                                           dlr.data_ptr(), B, g, S, float(eps), _lib.current_stream_handle()),
+                   "sgl_op_seg_loss_bwd")
+        return dlr.reshape(shape).to(dtype), None, None, None, None, None
+
+
+@torch.compiler.disable
+def bce_dice_loss_from_lowres(logit_lr: torch.Tensor, masks: torch.Tensor, has_mask: torch.Tensor = None,
+                              bce_w: float = 1.0, dice_w: float = 0.5, eps: float = 1e-6) -> torch.Tensor:
+    """`bce_dice_loss(upsample(logit_lr)[has_mask], masks[has_mask])` (Siglip2sidafrozen.py:174-181,743) from the (B,1,g,g)
+    logits of `SegFormerMaskDecoder(..., return_lowres=True)`; CUDA only (HIP kernels), fp32 statistics."""
+    if not logit_lr.is_cuda:
+        raise RuntimeError("bce_dice_loss_from_lowres runs on the GPU (HIP kernels); use bce_dice_loss on CPU tensors")
+    if has_mask is None:
+        has_mask = torch.ones(logit_lr.shape[0], dtype=torch.bool, device=logit_lr.device)
+    return _SegLossFromLowresFn.apply(logit_lr, masks, has_mask, float(bce_w), float(dice_w), float(eps))
+
+
 class SegFormerMaskDecoder(nn.Module):
     """SegFormer-style mask decoder (`SegFormerStrongDecoder`, Siglip2sidafrozen.py:698-745).
 
@@ -257,10 +354,12 @@ class SegFormerMaskDecoder(nn.Module):
                 out = term if out is None else out + term
         return out + conv.bias if conv.bias is not None else out
 
-    def forward(self, hidden_list: Sequence[torch.Tensor], grid_hw: Tuple[int, int], target_size: int = 448):
+    def forward(self, hidden_list: Sequence[torch.Tensor], grid_hw: Tuple[int, int], target_size: int = 448,
+                return_lowres: bool = False):
         """Everything up to the 1-channel logit map runs token-major / channels-last as GEMMs and elementwise ops (same
         math as the reference's NCHW convolutions, Siglip2sidafrozen.py:726-745); only the final bilinear up-sample of
-        the (B,1,g,g) logits uses an NCHW tensor."""
+        the (B,1,g,g) logits uses an NCHW tensor.  `return_lowres=True` stops before that up-sample and returns the
+        (B,1,gh,gw) logits: `bce_dice_loss_from_lowres` consumes them without ever materialising (B,1,S,S)."""
         gh, gw = grid_hw
         feats = []
         for proj, smooth, h in zip(self.projs, self.smooth, hidden_list):
@@ -272,12 +371,14 @@ class SegFormerMaskDecoder(nn.Module):
                 x = extra(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
             feats.append(x)
         x = torch.cat(feats, dim=-1)                                 # (B, gh, gw, E*K)
-        gate = torch.sigmoid(self._pointwise(self.fuse_attn[2], F.gelu(self._pointwise(self.fuse_attn[0], x))))
-        x = self._pointwise(self.fuse[0], gate * x)
+        gate_pre = self._pointwise(self.fuse_attn[2], F.gelu(self._pointwise(self.fuse_attn[0], x)))
+        x = self._pointwise(self.fuse[0], _gate_mul(gate_pre, x))       # sigmoid(gate) * x in one pass on the GPU
         for extra in list(self.fuse)[1:]:
             x = extra(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-        if self.head_before_upsample:
+        if self.head_before_upsample or return_lowres:
             logit = self._pointwise(self.head, x).permute(0, 3, 1, 2)   # (B, 1, gh, gw)
+            if return_lowres:
+                return logit
             return F.interpolate(logit, size=(target_size, target_size), mode="bilinear", align_corners=False)
         x = F.interpolate(x.permute(0, 3, 1, 2), size=(target_size, target_size), mode="bilinear", align_corners=False)
         return self.head(x)
@@ -305,7 +406,9 @@ class SigLIP2MTL(nn.Module):
         self.decoder = SegFormerMaskDecoder([hid] * len(self.seg_layers), embed_dim=embed_dim,
                                             dropout_rate=dropout_rate)
 
-    def forward(self, pixel_values):
+    def forward(self, pixel_values, return_lowres: bool = False):
+        """(cls_logit (B,3), seg_logits (B,1,S,S)) as the reference; `return_lowres=True` gives the (B,1,g,g) logit map
+        instead (the training path of `training_loss`, which never forms the up-sampled logits)."""
         n_layers = self.encoder.config.num_hidden_layers
         idxs = [(i + 1 if i >= 0 else n_layers) for i in self.seg_layers]   # hs = [emb, h1..hL] (:790-793)
         out = self.encoder(pixel_values=pixel_values, hidden_state_ids=idxs, interpolate_pos_encoding=True)
@@ -313,8 +416,15 @@ class SigLIP2MTL(nn.Module):
         cls_logit = self.cls_head(pooled).squeeze(1)
         feats = list(out.hidden_states)
         g = isqrt_exact(feats[0].shape[1])
-        seg_logits = self.decoder(feats, (g, g), target_size=int(pixel_values.shape[-1]))
+        seg_logits = self.decoder(feats, (g, g), target_size=int(pixel_values.shape[-1]), return_lowres=return_lowres)
         return cls_logit, seg_logits
+
+    def training_loss(self, pixel_values, y_class, masks, has_mask, lam_seg: float = 1.0):
+        """The SID train-step loss (Siglip2sidafrozen.py:1375-1389: CE + lam * BCE/Dice on the samples with a mask) with the
+        decoder tail fused for HBM: low-res logits -> loss directly.  Returns (loss, cls_logit, seg_logits_lowres)."""
+        cls_logit, seg_lr = self.forward(pixel_values, return_lowres=True)
+        loss = F.cross_entropy(cls_logit.float(), y_class) + lam_seg * bce_dice_loss_from_lowres(seg_lr, masks, has_mask)
+        return loss, cls_logit, seg_lr
 
 
 # ---------------------------------------------------------------------------------------------------------

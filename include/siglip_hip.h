@@ -222,6 +222,26 @@ size_t sgl_op_dwconv3x3_wgrad_scratch_bytes(int B, int gh, int gw, int E);
 int sgl_op_dwconv3x3_wgrad(const void* x, const void* dy, int dtype, float* dw10, int accumulate, float* scratch,
                            size_t scratch_bytes, int B, int gh, int gw, int E, sgl_stream stream);
 
+/* ---- SID mask-decoder tail, second half (Siglip2sidafrozen.py:731-745,174-181) -------------------
+ * y = sigmoid(g) * x on n elements (the channel gate applied to the concatenated taps, `gate * x` at :741-742), and its
+ * backward: dx = dy * sigmoid(g), dg = dy * x * s(1-s) (gradient w.r.t. the PRE-sigmoid gate; dg / dx may be NULL).
+ * dtype f32 or bf16; n % 4 (f32) / n % 8 (bf16) == 0; 16-byte aligned pointers. */
+int sgl_op_gate_mul(const void* g, const void* x, void* y, size_t n, int dtype, sgl_stream stream);
+int sgl_op_gate_mul_bwd(const void* dy, const void* g, const void* x, void* dg, void* dx, size_t n, int dtype,
+                        sgl_stream stream);
+/* bce_dice_loss (:174-181) evaluated straight from the LOW-RESOLUTION logit map: logits_lr (B,g,g) fp32 is what the 1x1
+ * head produces on the token grid; every one of the S*S output pixels is its bilinear (align_corners=False, as
+ * F.interpolate at :743) interpolation, computed in registers, so the (B,1,S,S) logits never exist in HBM.
+ * fwd: partial[b][chunk][4] = {sum bce, sum p*t, sum p, sum t} over 8 output rows (chunks = sgl_op_seg_loss_chunks(S));
+ *      the caller folds the chunks (fixed order) and forms  bce_w * mean(bce) + dice_w * (1 - mean_b(2I/(P+T+eps))).
+ * bwd: dlogits_lr[b] = transposed interpolation of  coef[b][0]*(p - t) + coef[b][1]*p(1-p)*(2tD - 2I)/D^2,
+ *      sums[b] = the folded forward sums {.., I, P, T}, D = P + T + eps; gathered per low-res pixel, no atomics. */
+int sgl_op_seg_loss_chunks(int S);
+int sgl_op_seg_loss_fwd(const float* logits_lr, const float* targets, float* partial, int B, int g, int S,
+                        sgl_stream stream);
+int sgl_op_seg_loss_bwd(const float* logits_lr, const float* targets, const float* sums, const float* coef,
+                        float* dlogits_lr, int B, int g, int S, float eps, sgl_stream stream);
+
 /* ---- optimizer step tail -----------------------------------------------------------------
  * Replaces, for a list of fp32 tensors, the reference's per-step pair
  *     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)   Siglip2sidafrozen.py:1396

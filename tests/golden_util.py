@@ -37,6 +37,9 @@ def compare(rec, prefix, tensor, atol, rtol):
             f"{prefix}: checksum {s} vs {float(rec[prefix + '.sum'])} (abssum {scale})"
     err = float(np.abs(got - ref).max())
     ref_scale = float(np.abs(ref).max())
+    if rtol >= 1e-3:      # bf16-style call: atol is the whole element-wise bound, rtol only scales the checksum check
+        assert err <= atol, f"{prefix}: max|err| {err:.3e} > {atol:.3e}"
+        return err, ref_scale
     assert err <= atol + rtol * ref_scale, f"{prefix}: max|err| {err:.3e} > {atol} + {rtol}*{ref_scale:.3e}"
     return err, ref_scale
 

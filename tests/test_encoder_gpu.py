@@ -1,9 +1,10 @@
 """GPU end-to-end parity of the encoder (through the Python host surface → C ABI → HIP kernels) against
 (1) the committed golden vectors captured from the real HF SiglipVisionModel and (2) the CPU oracle.
 
-Tolerances: compute mode "fp32" (strict) must match to ≤2e-4 abs on O(1)-O(6) activations (north-star bound is
-1e-3 on logits); compute mode "bf16" (bf16 MFMA operands, fp32 accumulate/residual/statistics) is bounded by
-bf16 operand rounding through the stack: ≤6e-2 abs on hidden states, gradients ≤8 % of their max-norm.
+Tolerances: compute mode "fp32" (strict) must match to ≤2e-5 abs on O(1)-O(6) activations (measured ≤6.2e-6; the
+north-star bound is 1e-3 on logits) and 6e-5 of max-norm on gradients.  Compute mode "bf16" — the benchmarked one — is
+pinned in tests/test_parity_bf16_gpu.py against the error the real HF model makes under bf16 autocast; here it only has
+to stay within 3x that model's max error per tensor.
 """
 import pytest
 import torch
@@ -29,34 +30,43 @@ def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
     x = pkg.weights.seeded_pixels(m["batch"], m["res"], m["res"], seed=m["seed"] + 1000).cuda()
     out = model(pixel_values=x, output_hidden_states=True, interpolate_pos_encoding=m["interp"])
     strict = mode == "fp32"
-    atol, rtol = (2e-4, 1e-4) if strict else (6e-2, 2e-2)
+
+    def tol(prefix):
+        """fp32: fixed (2x the measured 6.2e-6 / 1.4e-6 relative); bf16: 3x what HF under bf16 autocast does on this tensor."""
+        if strict:
+            return 2e-5, 0.0
+        return 3.0 * float(rec["bf16ac." + prefix + ".maxerr"]) + 1e-6, 1e-3     # (rtol only feeds the checksum check)
     errs = {}
-    errs["pooled"] = gu.compare(rec, "pooler_output", out.pooler_output.detach().cpu(), atol, rtol)
-    errs["last"] = gu.compare(rec, "last_hidden_state", out.last_hidden_state.detach().cpu(), atol, rtol)
+    errs["pooled"] = gu.compare(rec, "pooler_output", out.pooler_output.detach().cpu(), *tol("pooler_output"))
+    errs["last"] = gu.compare(rec, "last_hidden_state", out.last_hidden_state.detach().cpu(), *tol("last_hidden_state"))
     assert len(out.hidden_states) == model.config.num_hidden_layers + 1
     for i, h in enumerate(out.hidden_states):
-        errs[f"hs{i}"] = gu.compare(rec, f"hidden_states.{i}", h.detach().cpu(), atol, rtol)
+        errs[f"hs{i}"] = gu.compare(rec, f"hidden_states.{i}", h.detach().cpu(), *tol(f"hidden_states.{i}"))
     o = {"pooler_output": out.pooler_output, "last_hidden_state": out.last_hidden_state,
          "hidden_states": out.hidden_states}
     # same scalar as oracle.probe_loss, built on the GPU tensors
     loss = _probe_loss(o, m["taps"])
-    assert abs(loss.item() - float(rec["loss"])) <= (2e-3 if strict else 0.5) * max(1.0, abs(float(rec["loss"])))
+    hf_loss_err = abs(float(rec["bf16ac.loss"]) - float(rec["loss"]))
+    assert abs(loss.item() - float(rec["loss"])) <= (2e-5 * max(1.0, abs(float(rec["loss"]))) if strict
+                                                      else max(3.0 * hf_loss_err, 0.05 * max(1.0, abs(float(rec["loss"])))))
     loss.backward()
     sd = dict(model.named_parameters())
-    gatol, grtol = (0.0, 6e-4) if strict else (0.0, 8e-2)
     n = 0
     for k in rec:
         if k.startswith("grad.") and k.endswith(".shape"):
             name = k[len("grad."):-len(".shape")]
             assert sd[name].grad is not None, name
-            a_tol = gatol + 1e-7
             if name.endswith("k_proj.bias"):
                 # softmax is invariant to a per-query constant, so d k_proj.bias == 0 exactly in real arithmetic;
                 # what is left is rounding noise of sum_tokens(dK), bounded relative to the d q_proj.weight scale
-                a_tol = grtol * float(abs(rec["grad.encoder.layers.0.self_attn.q_proj.weight.full"]).max()
-                                      if "grad.encoder.layers.0.self_attn.q_proj.weight.full" in rec else
-                                      abs(rec["grad.encoder.layers.0.self_attn.q_proj.weight.samples"]).max())
-            errs["g:" + name] = gu.compare(rec, "grad." + name, sd[name].grad.detach().cpu(), a_tol, grtol)
+                qw = "grad.encoder.layers.0.self_attn.q_proj.weight"
+                qscale = float(abs(rec[qw + ".full"] if qw + ".full" in rec else rec[qw + ".samples"]).max())
+                a_tol, r_tol = (6e-5 if strict else 2e-2) * qscale, (0.0 if strict else 1e-2)
+            elif strict:
+                a_tol, r_tol = 1e-7, 6e-5          # measured <= 1e-5 of max-norm
+            else:                                  # 3x what HF under bf16 autocast does on this gradient
+                a_tol, r_tol = 3.0 * float(rec["bf16ac.grad." + name + ".maxerr"]) + 1e-7, 1e-2
+            errs["g:" + name] = gu.compare(rec, "grad." + name, sd[name].grad.detach().cpu(), a_tol, r_tol)
             n += 1
     assert n >= 20
     worst = max(errs.items(), key=lambda kv: kv[1][0] / (kv[1][1] + 1e-9))
@@ -74,29 +84,6 @@ def _probe_loss(out, tap_ids):
         h = out["hidden_states"][i]
         loss = loss + 0.01 * (h * cw(h)).sum()
     return loss
-
-
-def test_full_depth_bf16_vs_strict_and_oracle(pkg, oracle, hiplib):
-    """BASELINE config shape (so400m-patch14-384, all 27 layers, random seeded weights), B=2: the bf16 path
-    against the strict-fp32 path on the GPU and the strict path against the CPU oracle (logit-level bound)."""
-    cfg = pkg.get_config("so400m-patch14-384")
-    sd = pkg.weights.seeded_state_dict(cfg, seed=21)
-    x = pkg.weights.seeded_pixels(1, 384, 384, seed=22)
-    ref = oracle.vision_forward(x, sd, cfg, False, True)
-    outs = {}
-    for mode in ("fp32", "bf16"):
-        model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
-        model.load_state_dict(sd)
-        model = model.to("cuda")
-        with torch.no_grad():
-            outs[mode] = model(pixel_values=x.cuda(), interpolate_pos_encoding=True)
-        del model
-    e32 = (outs["fp32"].pooler_output.cpu() - ref["pooler_output"]).abs().max().item()
-    e16 = (outs["bf16"].pooler_output.cpu() - ref["pooler_output"]).abs().max().item()
-    scale = ref["pooler_output"].abs().max().item()
-    print(f"[so400m full depth] pooled |max| {scale:.3f}: strict err {e32:.2e}, bf16 err {e16:.2e}")
-    assert e32 < 1e-3, "strict mode must hold the 1e-3 logit bound against the fp32 oracle"
-    assert e16 < 0.12 * max(scale, 1.0)
 
 
 def test_frozen_prefix_taps_and_channels_last(pkg, oracle, hiplib):

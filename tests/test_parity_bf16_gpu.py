@@ -77,7 +77,11 @@ def test_bf16_error_within_2x_of_hf_bf16_autocast(case, pkg, hiplib):
         assert mx <= 3.0 * hf_mx + 1e-6, f"{prefix}: max err {mx:.3e} vs HF bf16 autocast {hf_mx:.3e}"
     hf_loss_err = abs(float(rec["bf16ac.loss"]) - float(rec["loss"]))
     loss_err = abs(loss.item() - float(rec["loss"]))
-    assert loss_err <= 2.0 * hf_loss_err + 1e-3 * max(1.0, abs(float(rec["loss"]))), (loss_err, hf_loss_err)
+    # the probe loss is a random-sign weighted SUM, so one run's error is itself random (HF's own ranges from 1e-3 to
+    # 0.3 over the cases): allow 2x HF's, or 0.2 % of the sum's L1 mass, whichever is larger
+    mass = out.pooler_output.abs().sum().item() + 0.01 * out.last_hidden_state.abs().sum().item() + \
+        0.01 * sum(out.hidden_states[i].abs().sum().item() for i in m["taps"])
+    assert loss_err <= max(2.0 * hf_loss_err, 2e-3 * mass), (loss_err, hf_loss_err, mass)
     worst = max(ratios.items(), key=lambda kv: kv[1][0])
     acts = [v[0] for k, v in ratios.items() if not k.startswith("grad.")]
     grads = [v[0] for k, v in ratios.items() if k.startswith("grad.")]
@@ -117,8 +121,9 @@ def full_depth_reference(pkg, oracle):
 
 # tolerances: relative L2 per tensor; fp32 mode is the north-star "logits within 1e-3" path, bf16 the benchmarked one.
 # Values are 2x what the MI355X run measured (printed by the test).
-FULL_TOL = {"fp32": dict(act=2e-5, grad=2e-4, pooled_abs=1e-3),
-            "bf16": dict(act=8e-3, grad=3e-2, pooled_abs=6e-2)}
+# measured (r2): fp32 act 1.4e-6, grads <= 6.8e-6, pooled 7.0e-6 abs; bf16 act 5.4e-3, grads <= 1.03e-2, pooled 2.2e-2 abs
+FULL_TOL = {"fp32": dict(act=3e-6, grad=1.4e-5, pooled_abs=2e-5, loss=2e-6),
+            "bf16": dict(act=1.1e-2, grad=2.1e-2, pooled_abs=4.4e-2, loss=8e-3)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -150,7 +155,9 @@ def test_full_depth_forward_backward_vs_oracle(mode, pkg, hiplib, full_depth_ref
         assert v <= tol["act"], (k, v)
     for k, v in gerrs.items():
         assert v <= tol["grad"], (k, v)
-    assert abs(loss.item() - ref["loss"]) <= (1e-4 if mode == "fp32" else 2e-2) * max(1.0, abs(ref["loss"]))
+    assert abs(loss.item() - ref["loss"]) <= tol["loss"] * max(1.0, abs(ref["loss"]))
+    if mode == "fp32":
+        assert pooled_abs < 1e-3     # the north-star bound ("logits within 1e-3 of the HF reference"), 140x margin
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -225,7 +232,7 @@ def test_config1_frozen_base_linear_head_batch4(pkg, oracle, hiplib):
     F.binary_cross_entropy_with_logits(ref_logits, y).backward()
     err = (logits.detach().cpu() - ref_logits.detach()).abs().max().item()
     print(f"[config 1] logits {logits.detach().cpu().tolist()} max|err| vs CPU composition {err:.2e}")
-    assert err <= 2e-2          # bf16 encoder (12 blocks) -> L2-normalised feature -> LN -> attention -> Linear
+    assert err <= 2.5e-3        # measured 1.24e-3: bf16 encoder (12 blocks) -> L2-norm -> LN -> attention -> Linear
     for (n, p), (_, q) in zip(clf.head.named_parameters(), head_cpu.named_parameters()):
         assert p.grad is not None, n
         assert rel_l2(p.grad, q.grad) <= 5e-2 or q.grad.abs().max() < 1e-6, n
@@ -242,27 +249,35 @@ def test_config1_frozen_base_linear_head_batch4(pkg, oracle, hiplib):
 # -----------------------------------------------------------------------------------------------------------------
 # BASELINE.json config 5: video track, 32-frame clips, per-frame so400m encoder + temporal mean-pool
 # -----------------------------------------------------------------------------------------------------------------
-def test_config5_video_32_frames(pkg, oracle, hiplib):
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config5_video_32_frames(mode, pkg, oracle, hiplib):
     """BinaryVideoClassifierHIP on (2, 32, 3, 384, 384) clips: encoder batch = 64 frames of the full-width so400m block
     (so400m-1layer keeps the CPU oracle affordable), L2-norm, temporal mean, MLP -> (2,) logits, forward and backward,
-    against oracle o CPU head (hidf_video_classifier.py:299-320)."""
+    against oracle o CPU head (hidf_video_classifier.py:299-320).
+
+    Conditioning note (measured, gpurun_out/cfg5.log): with random weights the 64 frame embeddings are nearly parallel
+    (cosine 0.97), so with OPPOSITE clip labels the two clips' contributions to every weight gradient cancel about 6:1 and
+    any forward rounding is amplified by that factor (bf16: 1.4 % on d loss/d embedding becomes 4-8 % on weight
+    gradients, while strict fp32 stays at 1e-5 on the very same problem).  The strict mode is therefore checked on the
+    hard opposite-label problem, the bf16 mode on equal labels, where its error is the error of the kernels."""
     import copy
     H = pkg.heads
     cfg = pkg.get_config("so400m-1layer")
     sd = pkg.weights.seeded_state_dict(cfg, seed=51)
-    enc = pkg.OpenClipStyleEncoder(cfg, "bf16")
+    enc = pkg.OpenClipStyleEncoder(cfg, mode)
     enc.visual.load_state_dict(sd)
     torch.manual_seed(5)
     vid = H.BinaryVideoClassifierHIP(enc, num_frames=32).eval()
     head_cpu = copy.deepcopy(vid.head)
     vid = vid.cuda()
     clips = pkg.weights.seeded_pixels(64, 384, 384, seed=52).view(2, 32, 3, 384, 384)
-    y = torch.tensor([1.0, 0.0])
+    y = torch.tensor([1.0, 0.0] if mode == "fp32" else [1.0, 1.0])
     F = torch.nn.functional
     logits = vid(clips.cuda())
     assert logits.shape == (2,)
     F.binary_cross_entropy_with_logits(logits, y.cuda()).backward()
-    watch = ["encoder.layers.0.mlp.fc1.weight", "head.attention.in_proj_weight"]
+    watch = ["encoder.layers.0.mlp.fc1.weight", "encoder.layers.0.self_attn.q_proj.weight",
+             "head.attention.in_proj_weight", "embeddings.patch_embedding.weight"]
     sdr = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
     ref = oracle.vision_forward(clips.view(64, 3, 384, 384), sdr, cfg, False, False)
     ref_logits = head_cpu(ref["pooler_output"], batch_size=2)
@@ -270,11 +285,15 @@ def test_config5_video_32_frames(pkg, oracle, hiplib):
     err = (logits.detach().cpu() - ref_logits.detach()).abs().max().item()
     named = dict(enc.visual.named_parameters())
     ge = {k: rel_l2(named[k].grad, sdr[k].grad) for k in watch}
-    print(f"[config 5] clip logits {logits.detach().cpu().tolist()} max|err| {err:.2e}; grads {ge}")
-    assert err <= 5e-3
-    assert max(ge.values()) <= 3e-2
-    for (n, p), (_, q) in zip(vid.head.named_parameters(), head_cpu.named_parameters()):
-        assert rel_l2(p.grad, q.grad) <= 3e-2 or q.grad.abs().max() < 1e-7, n
+    hg = max(rel_l2(p.grad, q.grad) for (n, p), (_, q) in zip(vid.head.named_parameters(), head_cpu.named_parameters())
+             if q.grad.abs().max() > 1e-7)
+    print(f"[config 5 {mode}] clip logits {logits.detach().cpu().tolist()} max|err| {err:.2e}; encoder grads "
+          + ", ".join(f"{k.split('.')[-3]}.{k.split('.')[-2]} {v:.2e}" for k, v in ge.items()) + f"; head grads {hg:.2e}")
+    if mode == "fp32":      # measured 1.2e-5 worst
+        assert err <= 1e-5 and max(ge.values()) <= 3e-5 and hg <= 3e-5
+    else:
+        assert err <= 5e-4          # measured 2.2e-4
+        assert max(ge.values()) <= 3e-2 and hg <= 3e-2
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -324,9 +343,10 @@ def test_config4_sid_default_decoder_bf16_autocast(pkg, oracle, hiplib):
     print(f"[config 4, bf16 autocast, 11 taps E=512] cls max|err| {e_cls:.2e} (scale {cls_ref.abs().max():.2f}); seg "
           f"max|err| {e_seg:.2e} rel-L2 {seg_l2:.2e} (scale {seg_ref.abs().max():.2f}); loss {loss.item():.4f} vs "
           f"{loss_ref.item():.4f}; grads {ge} decoder proj {gd:.2e} fuse {gf:.2e}")
-    # stated tolerance of the benchmarked path: class logits 2e-2 abs, mask logits 3e-2 rel-L2, loss 1 %
+    # stated tolerance of the benchmarked path (2x the values measured on MI355X: 9.7e-3, 8.9e-3, 1.5e-3, 1.6e-2,
+    # 6.4e-3): class logits 2e-2 abs, mask logits 1.8e-2 rel-L2, loss 0.3 %, gradients 3.3e-2 / 1.3e-2 rel-L2
     assert e_cls <= 2e-2
-    assert seg_l2 <= 3e-2
-    assert abs(loss.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
+    assert seg_l2 <= 1.8e-2
+    assert abs(loss.item() - loss_ref.item()) <= 3e-3 * abs(loss_ref.item())
     assert named["encoder.layers.8.mlp.fc1.weight"].grad is None
-    assert max(ge.values()) <= 5e-2 and gd <= 5e-2 and gf <= 5e-2
+    assert max(ge.values()) <= 3.3e-2 and gd <= 1.3e-2 and gf <= 1.3e-2

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("channels_last", [False, True])   # model and input as Siglip2sidafrozen.py:1191,1365 make them
 @pytest.mark.parametrize("freeze_below", [0, 1])   # 1: embeddings + block 0 frozen (only the dirty blocks are re-cast)
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 4e-3)])   # 2x the measured 4.2e-6 / 1.9e-3
 def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below, channels_last):
     pkg, oracle = entry.load_package(), entry.load_oracle()
     cfg = pkg.get_config("hostile")
@@ -82,4 +82,6 @@ def test_three_training_steps_track_the_cpu_reference(mode, tol, freeze_below, c
         r = diff.norm().item() / (moved.norm().item() + 1e-12)
         if r > worst:
             worst, who = r, k
-    assert worst <= (2e-2 if mode == "fp32" else 0.35), (worst, who)
+    print(f"[train loop {mode} freeze={freeze_below} cl={channels_last}] loss rel errs "
+          f"{[abs(a - b) / abs(b) for a, b in zip(losses, ref_losses)]} worst moved-relative {worst:.3e} ({who})")
+    assert worst <= (2e-3 if mode == "fp32" else 0.2), (worst, who)    # 2x the measured 8.7e-4 / 9.9e-2
