@@ -41,7 +41,10 @@ def parse():
                     help="secondary metric (SURVEY.md 8d): freeze embeddings and blocks < K as Siglip2sidafrozen.py:757-768")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--kernel-reps", type=int, default=20,
+                    help="launches per kernel for the roofline / breakdown legs; 0 skips them (clean rocprofv3 traces)")
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="skip the optimizer-step and full-train-step legs (clean rocprofv3 traces of the timed step)")
     return ap.parse_args()
 
 
@@ -111,7 +114,9 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
     except Exception:
         sclk = None
     traffic, alg_bytes = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):  # PMC FETCH_SIZE/WRITE_SIZE of the fc1-shape launch at this batch, measured offline
         ent = json.load(open(tpath)).get("by_batch", {}).get(str(batch))
         if ent and res == cfg.image_size and cfg.hidden_size == 1152:
@@ -121,9 +126,122 @@ def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
             "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
             "sustained_sclk_mhz": sclk,
             "sclk_note": "rocm-smi shader clock sampled while the kernel runs back to back for ~2 s; peak assumes 2400 MHz",
-            "traffic_note": "HBM+Infinity-Cache bytes of ONE fc1-shape launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                            f"profiles/r01_pmc_traffic.json); algorithmic bytes of that launch: {alg_bytes}",
+            "traffic_note": "bytes leaving the XCD L2s (HBM + Infinity Cache) for ONE fc1-shape launch: rocprofv3 "
+                            f"FETCH_SIZE x2 + WRITE_SIZE, collected OFFLINE in separate --pmc passes ({os.path.basename(tpath)}; "
+                            f"a process cannot read PMC counters for itself); algorithmic bytes of that launch: {alg_bytes}",
             "per_shape": per}
+
+
+def step_breakdown(pkg, cfg, batch, res, reps, nt_per_shape):
+    """Where one step's time goes, by kernel family, measured live: every family's kernel is launched `reps` times at the
+    step's own shapes between two HIP events on the launch stream, and its mean duration is multiplied by the number of
+    launches one step makes (L blocks: 4 forward NT GEMMs, 4 dX NT GEMMs, 4 dW TN GEMMs, 1 attention forward, 1 attention
+    backward, 2 LayerNorm forward, 2 LayerNorm backward).  `accounted_ms` against `ms_per_step` shows what is left for the
+    patch embedding, the pooling head, the weight-shadow casts, reductions and launch gaps."""
+    import math
+    lib = pkg.lib.load()
+    gh = res // cfg.patch_size
+    Ntok = gh * gh
+    M = batch * Ntok
+    D, I, L, Hh, dh = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.head_dim
+    Ip, DP = (I + 127) // 128 * 128, (dh + 15) // 16 * 16
+    st = torch.cuda.current_stream()
+    dev = "cuda"
+
+    def timeit(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps      # ms
+
+    fam = {"nt_fwd": sum(v["ms"] for v in nt_per_shape.values())}
+    # dX NT GEMMs: d(fc2)*gelu' [M,Ip]<-[M,D], d(fc1) [M,D]<-[M,Ip], d(out_proj) [M,D]<-[M,D], d(qkv) [M,D]<-[M,3D]
+    t_dx = 0.0
+    for N, K, epi in ((Ip, D, 4), (D, Ip, 0), (D, D, 0), (D, 3 * D, 0)):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        aux = torch.randn(M, N, device=dev).bfloat16() if epi == 4 else None
+        t_dx += timeit(lambda: lib.sgl_op_gemm_nt(1, A.data_ptr(), K, W.data_ptr(), K, M, N, K, epi, out.data_ptr(), N,
+                                                  None, 0, None, None, 0, None if aux is None else aux.data_ptr(), N,
+                                                  None, 1, 1, 1, 8, 8, 1, st.cuda_stream))
+        del A, W, out, aux
+    fam["nt_dx"] = t_dx
+    # dW TN GEMMs (deterministic split-K with scratch): fc2 [D,I], fc1 [I,D], out_proj [D,D], qkv [3D,D]
+    scratch = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    t_dw = 0.0
+    for N1, N2, l1, l2 in ((D, I, D, Ip), (I, D, Ip, D), (D, D, D, D), (3 * D, D, 3 * D, D)):
+        A = torch.randn(M, l1, device=dev).bfloat16()
+        Bm = torch.randn(M, l2, device=dev).bfloat16()
+        out = torch.empty(N1, N2, device=dev)
+        t_dw += timeit(lambda: lib.sgl_op_gemm_tn_ws(1, A.data_ptr(), l1, Bm.data_ptr(), l2, M, N1, N2, 0, out.data_ptr(),
+                                                     N2, 0, scratch.data_ptr(), scratch.numel(), st.cuda_stream))
+        del A, Bm, out
+    fam["tn_dw"] = t_dw
+    qkv = torch.zeros(3, batch, Hh, Ntok, DP, device=dev, dtype=torch.bfloat16)
+    qkv[..., :dh] = torch.randn(3, batch, Hh, Ntok, dh, device=dev).bfloat16()
+    o = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    do = torch.randn(M, D, device=dev).bfloat16()
+    lse = torch.empty(batch, Hh, Ntok, device=dev)
+    delta = torch.empty(batch, Hh, Ntok, device=dev)
+    dqkv = torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16)
+    fam["attn_fwd"] = timeit(lambda: lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(),
+                                                         o.data_ptr(), lse.data_ptr(), batch, Hh, Ntok, dh, DP,
+                                                         st.cuda_stream))
+    fam["attn_bwd"] = timeit(lambda: lib.sgl_op_attn_bwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(),
+                                                         o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                                         delta.data_ptr(), batch, Hh, Ntok, dh, DP, st.cuda_stream))
+    del qkv, o, do, dqkv
+    x = torch.randn(M, D, device=dev)
+    gam, bet = torch.randn(D, device=dev), torch.randn(D, device=dev)
+    y = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    dy = torch.randn(M, D, device=dev).bfloat16()
+    dres, dx = torch.randn(M, D, device=dev), torch.empty(M, D, device=dev)
+    dxlp = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    sc = torch.empty(32 << 20, device=dev, dtype=torch.uint8)
+    fam["ln_fwd"] = 2 * timeit(lambda: lib.sgl_op_layernorm_fwd(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(),
+                                                                1, mean.data_ptr(), rstd.data_ptr(), M, D, 1e-6,
+                                                                st.cuda_stream))
+    fam["ln_bwd"] = 2 * timeit(lambda: lib.sgl_op_layernorm_bwd(dy.data_ptr(), 1, x.data_ptr(), mean.data_ptr(),
+                                                                rstd.data_ptr(), gam.data_ptr(), dres.data_ptr(),
+                                                                dx.data_ptr(), dxlp.data_ptr(), 1, dg.data_ptr(),
+                                                                db.data_ptr(), sc.data_ptr(), sc.numel(), M, D,
+                                                                st.cuda_stream))
+    per_step = {k: round(v * L, 2) for k, v in fam.items()}
+    flops_layer = {"nt_fwd": 2.0 * M * (4 * D * D + 2 * D * I), "nt_dx": 2.0 * M * (4 * D * D + 2 * D * I),
+                   "tn_dw": 2.0 * M * (4 * D * D + 2 * D * I), "attn_fwd": 4.0 * batch * Hh * Ntok * Ntok * dh,
+                   "attn_bwd": 10.0 * batch * Hh * Ntok * Ntok * dh}
+    tf = {k: round(flops_layer[k] / (fam[k] * 1e-3) / 1e12, 1) for k in flops_layer}
+    return {"ms_per_step": per_step, "accounted_ms": round(sum(per_step.values()), 2), "tflops": tf,
+            "note": f"per-family kernel time = mean launch duration (HIP events, {reps} launches) x launches per step "
+                    f"({L} blocks); LayerNorm rows are x2 (two per block)"}
+
+
+def full_train_step(pkg, model, x, steps=3):
+    """fwd + bwd + FusedAdamW (clip + AdamW + bf16 weight-shadow writes in ONE pass: no separate re-cast) per step."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = pkg.FusedAdamW(params, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0).attach_encoder(model)
+
+    def step():
+        out = model(pixel_values=x, interpolate_pos_encoding=True)
+        out.pooler_output.square().mean().backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"images_per_sec": round(x.shape[0] / dt, 2), "ms_per_step": round(dt * 1e3, 2),
+            "what": "forward + backward + FusedAdamW(max_grad_norm) with the weight shadows written by the optimizer"}
 
 
 def optimizer_step_roofline(pkg, model, x, reps=10):
@@ -330,8 +448,15 @@ def main():
         print(f"[bench] {value:.1f} images/s, {ms_per_step:.1f} ms/step; measuring kernel roofline + CPU baseline ...",
               file=sys.stderr, flush=True)
         if world == 1:
-            line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
-            line["optimizer_step"] = optimizer_step_roofline(pkg, model, x)
+            if args.kernel_reps > 0:
+                line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
+                if args.mode == "bf16":
+                    line["step_breakdown"] = step_breakdown(pkg, cfg, args.batch, res, max(3, args.kernel_reps // 4),
+                                                            line["roofline"]["per_shape"])
+            if not args.no_optimizer:
+                line["optimizer_step"] = optimizer_step_roofline(pkg, model, x)
+                if args.freeze_below == 0:
+                    line["train_step_with_optimizer"] = full_train_step(pkg, model, x)
             del model
             torch.cuda.empty_cache()
             if not args.no_cpu_baseline:

@@ -100,6 +100,10 @@ struct AdamConst {
 
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float lr, float wd,
                                           const AdamConst& c) {
+  // no FMA contraction: every product and sum rounds once, as torch's separate elementwise kernels do, and — what matters
+  // here — identically in every kernel this is inlined into (the tiled shadow-writing path and the linear path gave
+  // parameters one ulp apart before, which bf16 weight rounding then amplifies into different training trajectories)
+#pragma clang fp contract(off)
   p = p * (1.0f - lr * wd);
   m = m + (g - m) * c.omb1;
   v = v * c.beta2 + (g * g) * c.omb2;

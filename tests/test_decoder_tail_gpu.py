@@ -82,6 +82,6 @@ def test_training_loss_equals_forward_then_mtl_loss(pkg, hiplib):
     assert seg_lr.shape == (3, 1, 4, 4) and torch.equal(cls, cls2)
     assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
     for n, p in model.named_parameters():
-        if n in want:
+        if n in want and not (n.endswith("k_proj.bias") or n.endswith("in_proj_bias")):   # exactly-zero gradients: noise
             err = (p.grad - want[n]).abs().max().item() / (want[n].abs().max().item() + 1e-30)
             assert err < 5e-5, (n, err)

@@ -293,7 +293,7 @@ def test_config5_video_32_frames(mode, pkg, oracle, hiplib):
         assert err <= 1e-5 and max(ge.values()) <= 3e-5 and hg <= 3e-5
     else:
         assert err <= 5e-4          # measured 2.2e-4
-        assert max(ge.values()) <= 3e-2 and hg <= 3e-2
+        assert max(ge.values()) <= 2.4e-2 and hg <= 2.2e-2      # measured 1.18e-2 / 1.10e-2
 
 
 # -----------------------------------------------------------------------------------------------------------------
