@@ -2,7 +2,7 @@
 
 Imported as ``siglip_amd`` via ``__graft_entry__.load_package()`` (the directory name has hyphens).
 """
-from . import config, weights, lib, heads, optim, weights_io  # noqa: F401
+from . import config, weights, lib, heads, optim, weights_io, preprocess  # noqa: F401
 from .config import SiglipVisionConfig, get_config, NAMED_CONFIGS  # noqa: F401
 from .encoder import (SiglipVisionModelHIP, OpenClipStyleEncoder, create_model_and_transforms,  # noqa: F401
                       VisionModelOutput)

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     if (t < QT) {
       const int qrow = qt * QT + t;
       s_l = (qrow < N) ? lse[(size_t)bh * N + qrow] * LOG2E : INFINITY;
-      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] : 0.f;
+      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] * scale : 0.f;   // pre-scaled: dS = p * fma(dP, scale, -delta*scale)
     }
   };
   auto store_stage = [&](int stage) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
         const int r = 4 * g4 + r3;
         const float p = fast_exp2(fmaf(S[r], c, -L4[r3]));
         S[r] = p;
-        dP[r] = p * (dP[r] - D4[r3]) * scale;
+        dP[r] = p * fmaf(dP[r], scale, -D4[r3]);
       }
     }
     bf16x8 pb[2], dsb[2];
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     dof[ks] = as_bf16x8(a_ldg(rdo, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
   }
   const float Lq = (q < N) ? lse[(size_t)bh * N + q] * LOG2E : INFINITY;
-  const float Dq = (q < N) ? delta[(size_t)bh * N + q] : 0.f;
+  const float Dq = (q < N) ? delta[(size_t)bh * N + q] * scale : 0.f;   // pre-scaled (see the kv kernel)
 
   u32x4 sk[NQ], sv[NQ];
   auto load_tile = [&](int kt) {
@@ -487,13 +487,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
       dP = MFMA32(va, dof[ks], dP);
     }
     // S[r], dP[r]: key row (r&3) + 8*(r>>2) + 4*hh of the tile, query = lane & 31
-    const bool last = (kt == ntiles - 1);
+    // the transposed K fragments of the dQ product depend only on the staged tile: request them now, so that their LDS
+    // latency runs under the softmax arithmetic below instead of in front of every MFMA
+    bf16x8 kt_frag[C::DT][2];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) kt_frag[dt][kk] = lds_trfrag(kimg, C::DSTR, kk, dt * 32, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float p = fast_exp2(fmaf(S[r], c, -Lq));
-      if (last && key >= N) p = 0.f;
-      dP[r] = p * (dP[r] - Dq) * scale;
+      const float p = fast_exp2(fmaf(S[r], c, -Lq));
+      dP[r] = p * fmaf(dP[r], scale, -Dq);
+    }
+    if (kt == ntiles - 1) {   // keys past N exist only in the last tile (wave-uniform branch: 4 VALU per score saved elsewhere)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= N) dP[r] = 0.f;
+      }
     }
     bf16x8 dsb[2];
     dsb[0] = pack8(dP, 0);
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) dq[dt] = MFMA32(lds_trfrag(kimg, C::DSTR, kk, dt * 32, lane), dsb[kk], dq[dt]);
+      for (int kk = 0; kk < 2; ++kk) dq[dt] = MFMA32(kt_frag[dt][kk], dsb[kk], dq[dt]);
     if (kt + 1 < ntiles) store_stage(cur ^ 1);
     __syncthreads();
   }

@@ -448,7 +448,11 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
   auto hs = [&](int l) { return hs_slots[l]; };
 
   // ---- embeddings
-  CK(im2col(pixels, channels_last, act + lay.a_im2col, dt, B, H, W, ctx->P, ctx->Kp, s));
+  if (channels_last == 2) {   // ready patch-major operand (sgl_op_preprocess): keep a copy where backward expects it
+    CK(hipMemcpyAsync(act + lay.a_im2col, pixels, (size_t)M * ctx->Kp * ctx->es, hipMemcpyDeviceToDevice, s));
+  } else {
+    CK(im2col(pixels, channels_last, act + lay.a_im2col, dt, B, H, W, ctx->P, ctx->Kp, s));
+  }
   const float* pos = w->pos;
   if (!(lay.gh == ctx->g0 && lay.gw == ctx->g0)) {
     float* pr = reinterpret_cast<float*>(act + lay.a_pos);

@@ -1,0 +1,144 @@
+// GPU input pipeline, first slice of SURVEY.md §8f row 2: the reference's per-batch GPU transform
+//     K.Resize(target_resolution, antialias=True) -> K.Normalize(mean=0.5, std=0.5)      cifake_binary_classifier.py:1791-1794
+//     (+ optionally MixUp: lam * images + (1 - lam) * images[index]                       cifake_binary_classifier.py:812-817)
+// fused with the patch gather of the patch-embedding convolution (TF:modeling_siglip.py:175-185): source images
+// (decoded uint8 NHWC bytes, or the float [0,1] NCHW tensors the reference's CPU transform produces) are resampled,
+// normalised and written straight into the bf16 patch-major A operand [B*gh*gw][Kp] of the patch GEMM — the fp32
+// (B,3,S,S) pixel tensor of the reference is never materialised and the im2col pass (encoder.hip) disappears.
+//
+// Resampling = separable triangle filter with the support stretched by the down-scale factor: the arithmetic of
+// torch's upsample_bilinear2d(antialias=True) (aten/native/cpu/UpSampleKernel.cpp, _compute_indices_weights_aa), which
+// is what torchvision Resize(antialias=True) runs in the reference's CPU transform (cifake...:1795-1797).  kornia (the
+// GPU transform) is not installed here: its result is "parity unpinned" (it blurs with a Gaussian before sampling).
+// HBM-bound; one thread = one operand element (coalesced bf16 stores along k), source taps come from L1/L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.cuh"
+#include "kernels.h"
+#include "siglip_hip.h"
+
+namespace sgl {
+
+struct AaAxis {
+  int lo, n;
+  float center, invscale, inv_total;
+};
+
+// taps of output index i along one axis (in -> out), weights w_j = tri((j + lo - center + 0.5) * invscale) / total
+__device__ __forceinline__ AaAxis aa_axis(int i, int in, float scale) {
+  AaAxis a;
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  a.invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  a.center = scale * ((float)i + 0.5f);
+  int lo = (int)(a.center - support + 0.5f);
+  if (lo < 0) lo = 0;
+  int hi = (int)(a.center + support + 0.5f);
+  if (hi > in) hi = in;
+  a.lo = lo;
+  a.n = hi - lo;
+  float total = 0.f;
+  for (int j = 0; j < a.n; ++j) {
+    float x = ((float)(j + lo) - a.center + 0.5f) * a.invscale;
+    x = x < 0.f ? -x : x;
+    total += x < 1.0f ? 1.0f - x : 0.f;
+  }
+  a.inv_total = total != 0.f ? 1.0f / total : 0.f;
+  return a;
+}
+__device__ __forceinline__ float aa_w(const AaAxis& a, int j) {
+  float x = ((float)(j + a.lo) - a.center + 0.5f) * a.invscale;
+  x = x < 0.f ? -x : x;
+  return (x < 1.0f ? 1.0f - x : 0.f) * a.inv_total;
+}
+
+template <bool SRC_U8>
+__device__ __forceinline__ float src_px(const void* src, int b, int c, int y, int x, int Hs, int Ws) {
+  if constexpr (SRC_U8)   // NHWC bytes
+    return (float)reinterpret_cast<const uint8_t*>(src)[(((size_t)b * Hs + y) * Ws + x) * 3 + c] * (1.0f / 255.0f);
+  else                    // NCHW float in [0, 1]
+    return reinterpret_cast<const float*>(src)[(((size_t)b * 3 + c) * Hs + y) * Ws + x];
+}
+
+template <bool SRC_U8>
+__device__ __forceinline__ float resample(const void* src, int b, int c, int oy, int ox, int Hs, int Ws, float sy,
+                                          float sx) {
+  if (sy == 1.0f && sx == 1.0f) return src_px<SRC_U8>(src, b, c, oy, ox, Hs, Ws);
+  const AaAxis ay = aa_axis(oy, Hs, sy), ax = aa_axis(ox, Ws, sx);
+  float acc = 0.f;
+  for (int jy = 0; jy < ay.n; ++jy) {
+    float row = 0.f;
+    for (int jx = 0; jx < ax.n; ++jx) row += aa_w(ax, jx) * src_px<SRC_U8>(src, b, c, ay.lo + jy, ax.lo + jx, Hs, Ws);
+    acc += aa_w(ay, jy) * row;
+  }
+  return acc;
+}
+
+// patch_major: out[(b*gh + gy)*gw + gx][k], k = c*P*P + ky*P + kx (k >= 3*P*P zero)   | else out[b][c][y][x] (NCHW)
+template <bool SRC_U8, typename TOut>
+__global__ __launch_bounds__(256) void preprocess_kernel(const void* __restrict__ src, TOut* __restrict__ out, int B,
+                                                         int Hs, int Ws, int S, int P, int Kp, int patch_major,
+                                                         float mean, float inv_std, const int* __restrict__ mix_index,
+                                                         float lam) {
+  const int g = S / P, K0 = 3 * P * P;
+  const size_t total = patch_major ? (size_t)B * g * g * Kp : (size_t)B * 3 * S * S;
+  const float sy = (float)Hs / (float)S, sx = (float)Ws / (float)S;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    int b, c, oy, ox;
+    bool live = true;
+    if (patch_major) {
+      const int k = (int)(idx % Kp);
+      const size_t m = idx / Kp;
+      const int gx = (int)(m % g), gy = (int)((m / g) % g);
+      b = (int)(m / ((size_t)g * g));
+      live = k < K0;
+      c = k / (P * P);
+      const int r = k - c * P * P;
+      oy = gy * P + r / P;
+      ox = gx * P + r % P;
+    } else {
+      ox = (int)(idx % S);
+      oy = (int)((idx / S) % S);
+      c = (int)((idx / ((size_t)S * S)) % 3);
+      b = (int)(idx / ((size_t)3 * S * S));
+    }
+    float v = 0.f;
+    if (live) {
+      v = resample<SRC_U8>(src, b, c, oy, ox, Hs, Ws, sy, sx);
+      if (mix_index) v = lam * v + (1.0f - lam) * resample<SRC_U8>(src, mix_index[b], c, oy, ox, Hs, Ws, sy, sx);
+      v = (v - mean) * inv_std;
+    }
+    Elem<TOut>::st(out + idx, v);
+  }
+}
+
+}  // namespace sgl
+
+extern "C" {
+
+int sgl_op_preprocess(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws, void* out, int out_dtype, int S, int P,
+                      int Kp, int patch_major, float mean, float std, const int* mix_index, float lam,
+                      sgl_stream stream) {
+  if (!src || !out) return SGL_ERR_NULL;
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || S <= 0 || std == 0.f) return SGL_ERR_BAD_SHAPE;
+  if (patch_major && (P <= 0 || S < P || Kp < 3 * P * P)) return SGL_ERR_BAD_SHAPE;
+  if (out_dtype != SGL_DTYPE_BF16 && out_dtype != SGL_DTYPE_F32) return SGL_ERR_UNSUPPORTED;
+  if ((float)Hs / (float)S > 16.f || (float)Ws / (float)S > 16.f) return SGL_ERR_UNSUPPORTED;  // tap loops stay short
+  const int g = patch_major ? S / P : 0;
+  const size_t total = patch_major ? (size_t)B * g * g * Kp : (size_t)B * 3 * S * S;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipStream_t s = (hipStream_t)stream;
+  const float inv_std = 1.0f / std;
+#define SGL_PP(U8, T)                                                                                               \
+  hipLaunchKernelGGL((sgl::preprocess_kernel<U8, T>), dim3(blocks), dim3(256), 0, s, src, (T*)out, B, Hs, Ws, S, P, Kp, \
+                     patch_major, mean, inv_std, mix_index, lam)
+  if (src_is_u8_nhwc) {
+    if (out_dtype == SGL_DTYPE_BF16) SGL_PP(true, sgl::bf16); else SGL_PP(true, float);
+  } else {
+    if (out_dtype == SGL_DTYPE_BF16) SGL_PP(false, sgl::bf16); else SGL_PP(false, float);
+  }
+#undef SGL_PP
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
+
+}  // extern "C"

@@ -129,7 +129,15 @@ def _module_of(handle: int) -> "SiglipVisionModelHIP":
     return mod
 
 
-def _geometry(mod, pixel_values):
+def _geometry(mod, pixel_values, layout=0, img_h=0, img_w=0):
+    if layout == 2:   # ready patch-major operand [B*N, Kp] (preprocess.to_patch_operand); geometry travels beside it
+        P = mod.config.patch_size
+        gh, gw = img_h // P, img_w // P
+        kp = (3 * P * P + 63) // 64 * 64
+        if pixel_values.dim() != 2 or pixel_values.shape[1] != kp or gh * gw == 0 or pixel_values.shape[0] % (gh * gw):
+            raise ValueError(f"patch operand must be (B*{gh * gw}, {kp}), got {tuple(pixel_values.shape)}")
+        B = pixel_values.shape[0] // (gh * gw)
+        return B, img_h, img_w, gh * gw, B * gh * gw, (gh, gw)
     if pixel_values.dim() != 4 or pixel_values.shape[1] != 3:
         raise ValueError(f"pixel_values must be (B,3,H,W), got {tuple(pixel_values.shape)}")
     B, _, H, W = pixel_values.shape
@@ -142,7 +150,8 @@ def _geometry(mod, pixel_values):
 
 @torch.library.custom_op("siglip_hip::encoder_fwd", mutates_args=())
 def encoder_fwd(pixel_values: torch.Tensor, params: Sequence[torch.Tensor], handle: int, train: bool, interp: bool,
-                want_pooled: bool, tap_ids: Sequence[int], first_trainable: int) -> List[torch.Tensor]:
+                want_pooled: bool, tap_ids: Sequence[int], first_trainable: int, layout: int, img_h: int,
+                img_w: int) -> List[torch.Tensor]:
     """sgl_forward_slots.  Returns [pooled (B,D) or empty, last_hidden_state (B,N,D), one (B,N,D) tensor per entry of
     tap_ids (distinct, ascending), saved (uint8 activation arena, empty when not training), hs_rest (the hidden-state
     slots nobody asked for: [n, B*N, D])].  No output aliases another."""
@@ -151,15 +160,21 @@ def encoder_fwd(pixel_values: torch.Tensor, params: Sequence[torch.Tensor], hand
     L, D = cfg.num_hidden_layers, cfg.hidden_size
     lib = _lib.load()
     px = pixel_values
-    if px.dtype != torch.float32:
-        px = px.float()
     channels_last = 0
-    if not px.is_contiguous():
-        if px.is_contiguous(memory_format=torch.channels_last):
-            channels_last = 1
-        else:
-            px = px.contiguous()
-    B, H, W, N, M, grid = _geometry(mod, px)
+    if layout == 2:
+        want = torch.bfloat16 if mod.compute_dtype == "bf16" else torch.float32
+        if px.dtype != want or not px.is_contiguous():
+            raise ValueError(f"patch operand must be contiguous {want} (the encoder's compute dtype)")
+        channels_last = 2
+    else:
+        if px.dtype != torch.float32:
+            px = px.float()
+        if not px.is_contiguous():
+            if px.is_contiguous(memory_format=torch.channels_last):
+                channels_last = 1
+            else:
+                px = px.contiguous()
+    B, H, W, N, M, grid = _geometry(mod, px, layout, img_h, img_w)
     if grid != (cfg.native_grid, cfg.native_grid) and not interp:
         raise ValueError(f"Input image size ({H}*{W}) doesn't match model native "
                          f"({cfg.image_size}*{cfg.image_size}); pass interpolate_pos_encoding=True")
@@ -197,11 +212,11 @@ def encoder_fwd(pixel_values: torch.Tensor, params: Sequence[torch.Tensor], hand
 
 
 @encoder_fwd.register_fake
-def _(pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable):
+def _(pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable, layout, img_h, img_w):
     mod = _module_of(handle)
     cfg = mod.config
     L, D = cfg.num_hidden_layers, cfg.hidden_size
-    B, H, W, N, M, _ = _geometry(mod, pixel_values)
+    B, H, W, N, M, _ = _geometry(mod, pixel_values, layout, img_h, img_w)
     if not all(isinstance(v, int) for v in (B, H, W)):
         raise RuntimeError("siglip_hip::encoder_fwd needs static image shapes under torch.compile (dynamic=False)")
     new = pixel_values.new_empty
@@ -322,10 +337,10 @@ def _(grads, taps, saved, hs_rest, params, handle, image_hw, interp, want_pooled
 
 
 def _encoder_setup_context(ctx, inputs, output):
-    pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable = inputs
+    pixel_values, params, handle, train, interp, want_pooled, tap_ids, first_trainable, layout, img_h, img_w = inputs
     ctx.set_materialize_grads(False)
     ctx.handle, ctx.interp, ctx.want_pooled, ctx.tap_ids = handle, interp, want_pooled, list(tap_ids)
-    ctx.image_hw = [int(pixel_values.shape[2]), int(pixel_values.shape[3])]
+    ctx.image_hw = [int(img_h), int(img_w)] if layout == 2 else [int(pixel_values.shape[2]), int(pixel_values.shape[3])]
     ctx.ntaps, ctx.nparams, ctx.train = len(tap_ids), len(params), train
     if train:
         # saving the taps (outputs) makes autograd's version counter catch a consumer's in-place edit of a hidden state
@@ -354,7 +369,7 @@ def _encoder_backward(ctx, grads):
         for i, off, n in entries:
             pgrads[i] = flat[off:off + n].view(params[i].shape)
     # pytree structure of the inputs: an EMPTY int list is a list node, a non-empty one a leaf (torch/_library/autograd.py)
-    return None, pgrads, None, None, None, None, ([] if len(ctx.tap_ids) == 0 else None), None
+    return None, pgrads, None, None, None, None, ([] if len(ctx.tap_ids) == 0 else None), None, None, None, None
 
 
 encoder_fwd.register_autograd(_encoder_backward, setup_context=_encoder_setup_context)
@@ -466,9 +481,16 @@ class SiglipVisionModelHIP(nn.Module):
             state_dict = weights_io.encoder_state_from_checkpoint(state_dict, self.config)
         return super().load_state_dict(dict(state_dict), strict=strict, **kw)
 
-    def forward(self, pixel_values, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
-                hidden_state_ids=None, **_):
-        """Traceable by Dynamo: everything device-side happens inside ``torch.ops.siglip_hip.encoder_fwd``."""
+    def forward(self, pixel_values=None, output_hidden_states: bool = False, interpolate_pos_encoding: bool = False,
+                hidden_state_ids=None, patches=None, **_):
+        """Traceable by Dynamo: everything device-side happens inside ``torch.ops.siglip_hip.encoder_fwd``.
+        ``patches`` (a ``preprocess.PatchOperand``) replaces ``pixel_values``: the resized + normalised images already
+        in the patch GEMM's operand layout, so neither an fp32 (B,3,S,S) tensor nor the im2col pass exists."""
+        layout, img_h, img_w = 0, 0, 0
+        if patches is not None:
+            if pixel_values is not None:
+                raise ValueError("pass either pixel_values or patches")
+            pixel_values, layout, img_h, img_w = patches.data, 2, int(patches.height), int(patches.width)
         if pixel_values.device.type != "cuda":
             raise RuntimeError("SiglipVisionModelHIP runs only on an AMD GPU through libsiglip_hip.so "
                                "(no CPU fallback); move the model and pixel_values to 'cuda'")
@@ -494,7 +516,8 @@ class SiglipVisionModelHIP(nn.Module):
                     first = int(grp[5:])
                     break
         outs = torch.ops.siglip_hip.encoder_fwd(pixel_values, params, self._handle, train,
-                                                bool(interpolate_pos_encoding), self.use_head, uniq, first)
+                                                bool(interpolate_pos_encoding), self.use_head, uniq, first, layout, img_h,
+                                                img_w)
         pooled = outs[0] if self.use_head else None
         hs = tuple(outs[2 + uniq.index(i)] for i in tap_ids) if tap_ids else None
         return VisionModelOutput(last_hidden_state=outs[1], pooler_output=pooled, hidden_states=hs)
@@ -843,8 +866,8 @@ class OpenClipStyleEncoder(nn.Module):
                 name = root + tail
             yield name, p
 
-    def encode_image(self, x, normalize: bool = False):
-        out = self.visual(pixel_values=x, interpolate_pos_encoding=False)
+    def encode_image(self, x=None, normalize: bool = False, patches=None):
+        out = self.visual(pixel_values=x, interpolate_pos_encoding=False, patches=patches)
         f = out.pooler_output
         if normalize:
             f = f / f.norm(dim=-1, keepdim=True)

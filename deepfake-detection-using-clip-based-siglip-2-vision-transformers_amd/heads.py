@@ -683,6 +683,42 @@ class CoralCalibrator:
         return p / (p.sum(dim=-1, keepdim=True) + 1e-8)
 
 
+@torch.no_grad()
+def core_signals_batched(z_sigs: torch.Tensor, crop_weights: torch.Tensor, z_freqs: torch.Tensor, z_rot: torch.Tensor,
+                         fusion_head: nn.Module, coral: "CoralCalibrator", freq_temp: float = 1.25,
+                         coral_temp: float = 1.0) -> dict:
+    """The inference-side tail of the app's `detect_core` (appv3.py:3221-3300) for a BATCH of images, entirely on the
+    device: weighted multi-crop logits, the 90-degree dual-view stabiliser, the 2->1 fusion head on probabilities, the
+    temperature-scaled raw probability, the CORAL ordinal distribution with its Gaussian-smoothed probability and entropy,
+    and the conservative blend.  The app does this per image with ~12 `.item()` round trips; here every quantity is a
+    (B,) / (B,5) tensor and nothing synchronises.
+
+    z_sigs, z_freqs: (B, C) per-crop logits of the SigLIP classifier and the frequency MLP (C = 9 crops,
+    make_multicrops); crop_weights: (C,); z_rot: (B,) logit of the rotated view."""
+    dev = z_sigs.device
+    w = crop_weights.to(dev, torch.float32)
+    z_sig0 = (z_sigs.float() * w).sum(-1)
+    z_freq = (z_freqs.float() * w).sum(-1)
+    visual_prob = 0.6 * torch.sigmoid(z_sig0) + 0.4 * torch.sigmoid(z_rot.float())
+    pc = visual_prob.clamp(1e-6, 1 - 1e-6)
+    z_sig = torch.log(pc / (1 - pc))                                     # _logit (appv3.py:3150-3152)
+    p_freq = torch.sigmoid(z_freq / freq_temp)
+    z = fusion_head(torch.stack([visual_prob, p_freq], dim=-1)).reshape(-1)
+    z_scaled = z / max(float(coral_temp), 1e-3)
+    p_fake_raw = torch.sigmoid(z_scaled)
+    risk_probs = coral.probs_batch(z_scaled)                             # (B, 5)
+    risk_idx = risk_probs.argmax(-1)
+    risk_vec = torch.arange(5, dtype=torch.float32, device=dev)
+    mu = (risk_probs * risk_vec).sum(-1)
+    var = (risk_probs * (risk_vec - mu[:, None]) ** 2).sum(-1)
+    p_coral = (mu / 4.0 + 0.5 * var).clamp(0.0, 1.0)
+    entropy = -(risk_probs * torch.log(risk_probs + 1e-8)).sum(-1)
+    p_blend = (0.70 * p_fake_raw + 0.30 * p_coral).clamp(0.0, 1.0)
+    return {"z_sig": z_sig, "z_freq": z_freq, "visual_prob": visual_prob, "p_freq": p_freq, "z": z, "z_scaled": z_scaled,
+            "p_fake_raw": p_fake_raw, "risk_probs": risk_probs, "risk_idx": risk_idx, "p_fake_coral": p_coral,
+            "coral_entropy": entropy, "p_blend": p_blend}
+
+
 RISK_NAMES = ["REAL", "LEAN_REAL", "BORDERLINE", "LEAN_FAKE", "FAKE"]
 
 

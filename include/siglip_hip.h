@@ -116,8 +116,10 @@ int sgl_prepare_weights_dirty(sgl_ctx* ctx, const sgl_weights* w, void* shadow, 
                               const unsigned char* layer_dirty, int globals_dirty, sgl_stream stream);
 
 /* ---- forward ---------------------------------------------------------------------------------------- */
-/* pixels: fp32 (B,3,H,W) NCHW, or NHWC storage when channels_last != 0 (reference .to(channels_last),
+/* pixels: fp32 (B,3,H,W) NCHW, or NHWC storage when channels_last == 1 (reference .to(channels_last),
  *         Siglip2sidafrozen.py:1191,1365).  Grid = (H / p, W / p) as in a "valid" conv (384 / 14 = 27).
+ *         channels_last == 2: `pixels` is instead the ready patch-major operand [B*grid^2][round_up(3p^2,64)] in the
+ *         compute dtype (sgl_op_preprocess, patch_major): the gather pass is skipped (H, W still give the geometry).
  * hidden_states: fp32 [hs_slots][B*N][D]; slot l holds hidden_states[l] of the HF output (0 = embeddings,
  *         L = last block output before post_layernorm).  hs_slots = L+1 keeps all of them (required when
  *         saved != NULL); hs_slots = 2 ping-pongs (inference without taps).
@@ -221,6 +223,21 @@ int sgl_op_dwconv3x3(const void* x, int dtype, const float* w9, const float* bia
 size_t sgl_op_dwconv3x3_wgrad_scratch_bytes(int B, int gh, int gw, int E);
 int sgl_op_dwconv3x3_wgrad(const void* x, const void* dy, int dtype, float* dw10, int accumulate, float* scratch,
                            size_t scratch_bytes, int B, int gh, int gw, int E, sgl_stream stream);
+
+/* ---- GPU input pipeline (first slice) ----------------------------------------------------------
+ * K.Resize(S, antialias=True) -> [MixUp] -> K.Normalize(mean, std) of the reference's per-batch GPU transform
+ * (cifake_binary_classifier.py:1791-1794,812-817), optionally fused with the patch gather of the patch-embedding
+ * convolution: src is uint8 NHWC (B,Hs,Ws,3) decoded bytes (src_is_u8_nhwc != 0, scaled by 1/255) or float32 NCHW
+ * (B,3,Hs,Ws) in [0,1]; the image is resampled to S x S with torch's antialiased bilinear filter
+ * (upsample_bilinear2d(antialias=True)); mix_index != NULL blends image b with image mix_index[b] (device int32[B]):
+ * lam*img[b] + (1-lam)*img[mix_index[b]].
+ *   patch_major != 0: out is the patch GEMM's A operand [B*(S/P)^2][Kp] in out_dtype (k = c*P*P + ky*P + kx, columns
+ *                     >= 3*P*P zero), Kp as the encoder uses it (round_up(3*P*P, 64)): pass it to sgl_forward_slots with
+ *                     channels_last = 2 and the im2col pass is skipped;
+ *   patch_major == 0: out is (B,3,S,S) NCHW in out_dtype (the tensor the reference's transform returns). */
+int sgl_op_preprocess(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws, void* out, int out_dtype, int S, int P,
+                      int Kp, int patch_major, float mean, float std, const int* mix_index, float lam,
+                      sgl_stream stream);
 
 /* ---- SID mask-decoder tail, second half (Siglip2sidafrozen.py:731-745,174-181) -------------------
  * y = sigmoid(g) * x on n elements (the channel gate applied to the concatenated taps, `gate * x` at :741-742), and its

@@ -155,7 +155,7 @@ def test_custom_ops_are_registered_with_fake_impls(pkg):
     params = m._flat_params()
     with FakeTensorMode(allow_non_fake_inputs=True):
         x = torch.empty(2, 3, 32, 32)
-        outs = torch.ops.siglip_hip.encoder_fwd(x, params, m._handle, True, False, True, [1, 3], 0)
+        outs = torch.ops.siglip_hip.encoder_fwd(x, params, m._handle, True, False, True, [1, 3], 0, 0, 0, 0)
     assert [tuple(o.shape) for o in outs[:4]] == [(2, 64), (2, 4, 64), (2, 4, 64), (2, 4, 64)]
     assert outs[4].dtype == torch.uint8 and outs[4].numel() == m._sizes(2, 32, 32, True)[1]
     assert tuple(outs[5].shape) == (2, 8, 64)          # 4 slots, 2 of them handed out as taps

@@ -144,3 +144,39 @@ def test_mtl_loss_and_shapes(pkg, dev):
     assert torch.allclose(H.mtl_loss(cls, seg, y, m, torch.zeros(4, dtype=torch.bool, device=dev)), base)
     full = H.mtl_loss(cls, seg, y, m, hm, lam_seg=0.7)
     assert torch.allclose(full, base + 0.7 * H.bce_dice_loss(seg[hm], m[hm]))
+
+
+def test_batched_inference_signals_equal_the_apps_per_image_loop(pkg, dev):
+    """heads.core_signals_batched against a scalar restatement of appv3.py:3221-3300 (`detect_core` after the encoder):
+    the app's own arithmetic, one image at a time with Python floats, on the shipped fusion head and CORAL cut-points."""
+    from safetensors.torch import load_file
+    H = pkg.heads
+    fh = H.LinearFusionHead()
+    fh.load_state_dict(load_file(os.path.join(REF_SIGLIP, "fusion_head.safetensors")))
+    cc = H.CoralCalibrator(json.load(open(os.path.join(REF_SIGLIP, "coral_cutpoints.json"))))
+    temp = json.load(open(os.path.join(REF_SIGLIP, "coral_temp.json")))["temperature"]
+    B, C = 7, 9
+    z_sigs, z_freqs = T(pkg, "app_zs", (B, C), 4.0), T(pkg, "app_zf", (B, C), 3.0)
+    z_rot = T(pkg, "app_zr", (B,), 4.0)
+    w = torch.tensor([0.2] + [0.1] * 8)
+    got = H.core_signals_batched(z_sigs.to(dev), w.to(dev), z_freqs.to(dev), z_rot.to(dev), fh.to(dev), cc, 1.25, temp)
+    sig = lambda v: 1.0 / (1.0 + math.exp(-v))
+    for b in range(B):
+        z_sig = float((z_sigs[b] * w).sum())
+        z_freq = float((z_freqs[b] * w).sum())
+        visual = 0.6 * sig(z_sig) + 0.4 * sig(float(z_rot[b]))
+        p_freq = sig(z_freq / 1.25)
+        z = float(fh.cpu()(torch.tensor([[visual, p_freq]], dtype=torch.float32)).item())
+        z_scaled = z / max(temp, 1e-3)
+        idx, probs = cc.predict(torch.tensor(z_scaled))
+        mu = float((torch.arange(5.0) * probs).sum())
+        var = float((probs * (torch.arange(5.0) - mu) ** 2).sum())
+        want = {"z_sig": H._logit(visual), "z_freq": z_freq, "visual_prob": visual, "p_freq": p_freq, "z": z,
+                "z_scaled": z_scaled, "p_fake_raw": sig(z_scaled), "p_fake_coral": max(0.0, min(1.0, mu / 4 + 0.5 * var)),
+                "coral_entropy": float(-(probs * torch.log(probs + 1e-8)).sum()),
+                "p_blend": max(0.0, min(1.0, 0.7 * sig(z_scaled) + 0.3 * max(0.0, min(1.0, mu / 4 + 0.5 * var))))}
+        for k, v in want.items():
+            assert abs(float(got[k][b]) - v) <= 2e-5 * max(1.0, abs(v)), (k, b, float(got[k][b]), v)
+        assert int(got["risk_idx"][b]) == idx
+        close(got["risk_probs"][b], probs.numpy(), 1e-5)
+    fh.to(dev)
