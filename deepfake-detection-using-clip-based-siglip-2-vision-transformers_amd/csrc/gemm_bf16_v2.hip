@@ -672,8 +672,12 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
     }
     // band height of the grouped tile order: 8 row-tiles for wide outputs, 4 when there are few column tiles (measured
     // on one box: qkv N=3456 +3 %, fc2 N=1152 +1.5 % with 4; fc1 N=4352 best with 8).  SGL_BAND overrides.
-    static const int band_env = getenv("SGL_BAND") ? atoi(getenv("SGL_BAND")) : 0;   // < 0: B-stationary, cgw = -value
-    const int band_h = band_env != 0 ? band_env : (tiles_n >= 16 ? 8 : 4);
+    // Tile order.  Default (round 2): B-stationary with column groups of 8 — same speed as the round-1 grouped bands
+    // (+-1 % over the encoder's eight shapes) but 35 % fewer bytes leave the XCD L2s at the bench batch (rocprofv3
+    // FETCH_SIZE: 2.42 -> 1.56 GB per fc1 launch at B = 128, profiles/r02_pmc_traffic.json).  SGL_BAND > 0 selects the
+    // grouped bands of that height (8 / 4 were the round-1 choices), SGL_BAND < 0 another column-group width.
+    static const int band_env = getenv("SGL_BAND") ? atoi(getenv("SGL_BAND")) : 0;
+    const int band_h = band_env != 0 ? band_env : -8;
     int grid6 = grid;
     if (band_h < 0) grid6 = 8 * (((tiles_m + 7) / 8) * tiles_n);   // 8 XCDs x the largest per-XCD tile count
     static const bool skip_epi = getenv("SGL_NT6_SKIP_EPI") != nullptr;
