@@ -338,13 +338,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     f32x16 S, dP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+    // ---- phase A: S = Q·Kᵀ, dP = dO·Vᵀ.  All row fragments and the tile's lse / delta rows are requested up front and
+    // the schedule is pinned (sched_group_barrier): left alone, hipcc issued two LDS reads and waited for them in front of
+    // EVERY MFMA, so the matrix pipe idled for an LDS round trip 22 times per tile (PMC: waves parked 43 % of the time).
+    bf16x8 qa[C::KS], da[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      const bf16x8 qa = lds_row8(qimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
-      const bf16x8 da = lds_row8(dimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
-      S = MFMA32(qa, kfr[ks], S);
-      dP = MFMA32(da, vfr[ks], dP);
+      qa[ks] = lds_row8(qimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
+      da[ks] = lds_row8(dimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
     }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      S = MFMA32(qa[ks], kfr[ks], S);
+      dP = MFMA32(da[ks], vfr[ks], dP);
+    }
+    if constexpr (C::KS == 5) {   // 4 fragments in flight ahead of the MFMA chain
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the first two transposed fragments of phase B depend only on the staged tile: their latency runs under the
+    // softmax arithmetic.  Fragment order: (dv, dk) for (dt, kk) = (0,0) (0,1) (1,0) ...
+    constexpr int NF = 2 * 2 * C::DT;
+    bf16x8 fr[NF];
+    auto frag = [&](int i) {
+      const int which = i & 1, kk = (i >> 1) & 1, dt = i >> 2;
+      return lds_trfrag(which ? qimg : dimg, C::DSTR, kk, dt * 32, lane);
+    };
+    constexpr int PRE = NF < 2 ? NF : 2;
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) fr[i] = frag(i);
+    __builtin_amdgcn_sched_barrier(0);
     // S[r], dP[r]: query row (r&3) + 8*(r>>2) + 4*hh of the tile, key = lane & 31
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -363,13 +392,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     pb[1] = pack8(S, 8);
     dsb[0] = pack8(dP, 0);
     dsb[1] = pack8(dP, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B: dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS, two fragments ahead of the MFMA that consumes them
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+    for (int i = 0; i < NF; ++i) {
+      if (i + PRE < NF) fr[i + PRE] = frag(i + PRE);
+      const int which = i & 1, kk = (i >> 1) & 1, dt = i >> 2;
+      if (which) dk[dt] = MFMA32(fr[i], dsb[kk], dk[dt]);
+      else dv[dt] = MFMA32(fr[i], pb[kk], dv[dt]);
+    }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        dv[dt] = MFMA32(lds_trfrag(dimg, C::DSTR, kk, dt * 32, lane), pb[kk], dv[dt]);
-        dk[dt] = MFMA32(lds_trfrag(qimg, C::DSTR, kk, dt * 32, lane), dsb[kk], dk[dt]);
-      }
+    for (int i = 0; i < NF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i + PRE < NF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (qt + 1 < ntiles) store_stage(cur ^ 1);
     __syncthreads();
   }
@@ -479,13 +516,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     f32x16 S, dP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+    // phase A: Sᵀ = K·Qᵀ, dPᵀ = V·dOᵀ with the row fragments requested up front and the schedule pinned (see the kv kernel)
+    bf16x8 ka[C::KS], va[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      const bf16x8 ka = lds_row8(kimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
-      const bf16x8 va = lds_row8(vimg + li * C::RSTR + (16 * ks + 8 * hh) * 2);
-      S = MFMA32(ka, qf[ks], S);
-      dP = MFMA32(va, dof[ks], dP);
+      ka[ks] = lds_row8(kimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
+      va[ks] = lds_row8(vimg + li * C::RSTR + (16 * ks + 8 * hh) * 2);
     }
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      S = MFMA32(ka[ks], qf[ks], S);
+      dP = MFMA32(va[ks], dof[ks], dP);
+    }
+    if constexpr (C::KS == 5) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // S[r], dP[r]: key row (r&3) + 8*(r>>2) + 4*hh of the tile, query = lane & 31
     // the transposed K fragments of the dQ product depend only on the staged tile: request them now, so that their LDS
     // latency runs under the softmax arithmetic below instead of in front of every MFMA
@@ -494,6 +546,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) kt_frag[dt][kk] = lds_trfrag(kimg, C::DSTR, kk, dt * 32, lane);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = fast_exp2(fmaf(S[r], c, -Lq));
