@@ -226,28 +226,57 @@ hipError_t pos_resize(const float* table, int g0, float* out, int gh, int gw, in
   return hipGetLastError();
 }
 
-// transpose of the above: dtable (+)= Wᵀ · dout.  16 fp32 atomics per output element; the table is tiny.
+// transpose of the above: dtable[iy][ix][d] (+)= sum over outputs (oy, ox) of wy(oy -> iy) * wx(ox -> ix) * dout[oy][ox][d].
+// GATHER form, one thread per table element, contributions added in a fixed (oy, ox) order: bitwise reproducible (the
+// round-1 scatter used 16 fp32 atomics per output element).  The outputs that can touch table row iy lie in a short range
+// around (iy + 0.5) * gh / g0; it is scanned conservatively (+-3 source rows plus the border clamp) and the exact test is
+// "one of the output's four clamped taps equals iy".
+__device__ __forceinline__ void tap_range(int i, int g0, int gout, int& lo, int& hi) {
+  const float inv = (float)gout / (float)g0;
+  lo = (int)floorf(((float)i - 3.0f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 3.0f + 0.5f) * inv - 0.5f) + 1;
+  if (i == 0) lo = 0;                 // border entries also collect the clamped taps of every output near the edge
+  if (i == g0 - 1) hi = gout - 1;
+  if (lo < 0) lo = 0;
+  if (hi > gout - 1) hi = gout - 1;
+}
 __global__ __launch_bounds__(256) void pos_resize_bwd_kernel(const float* __restrict__ dout, int gh, int gw,
                                                              float* __restrict__ dtable, int g0, int D) {
-  const size_t total = (size_t)gh * gw * D;
+  const size_t total = (size_t)g0 * g0 * D;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int d = (int)(idx % D);
-  const int o = (int)(idx / D);
-  const int oy = o / gw, ox = o - oy * gw;
-  int iy[4], ix[4];
-  float wy[4], wx[4];
-  cubic_taps(oy, g0, gh, iy, wy);
-  cubic_taps(ox, g0, gw, ix, wx);
-  const float g = dout[idx];
+  const int e = (int)(idx / D);
+  const int ty = e / g0, tx = e - ty * g0;
+  int ylo, yhi, xlo, xhi;
+  tap_range(ty, g0, gh, ylo, yhi);
+  tap_range(tx, g0, gw, xlo, xhi);
+  float acc = 0.f;
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    int iy[4];
+    float wy[4];
+    cubic_taps(oy, g0, gh, iy, wy);
+    float wyy = 0.f;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) wyy += (iy[a] == ty) ? wy[a] : 0.f;
+    if (wyy == 0.f) continue;
+    float rowacc = 0.f;
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      int ix[4];
+      float wx[4];
+      cubic_taps(ox, g0, gw, ix, wx);
+      float wxx = 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) atomicAdd(dtable + ((size_t)iy[a] * g0 + ix[b]) * D + d, g * wy[a] * wx[b]);
+      for (int b2 = 0; b2 < 4; ++b2) wxx += (ix[b2] == tx) ? wx[b2] : 0.f;
+      if (wxx != 0.f) rowacc += wxx * dout[((size_t)oy * gw + ox) * D + d];
+    }
+    acc += wyy * rowacc;
+  }
+  dtable[idx] += acc;
 }
 hipError_t pos_resize_bwd(const float* dout, int gh, int gw, float* dtable, int g0, int D, hipStream_t s) {
-  const size_t total = (size_t)gh * gw * D;
-  if (total == 0) return hipSuccess;
+  const size_t total = (size_t)g0 * g0 * D;
+  if (total == 0 || gh * gw == 0) return hipSuccess;
   hipLaunchKernelGGL(pos_resize_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dout, gh, gw,
                      dtable, g0, D);
   return hipGetLastError();

@@ -37,24 +37,32 @@ class _TapProj(nn.Module):
         return _linear_tokens(x, self.proj.weight, self.proj.bias)
 
 
-_W_CACHE: dict = {}       # (data_ptr, shape) -> (version, bf16 W, bf16 Wᵀ or None)
+_W_CACHE: dict = {}       # id(parameter) -> (weakref(parameter), version, data_ptr, bf16 W, bf16 Wᵀ or None)
 _SCRATCH: dict = {}       # device -> 64 MiB split-K scratch, reused by every call (stream-ordered)
 
 
 def _cached_bf16(weight: torch.Tensor, want_t: bool):
     """bf16 copy (and, on demand, transposed copy) of a weight, re-made only when the parameter changed (optimizer steps
-    bump ``_version``): the decoder has ~40 Linear layers and used to re-cast + re-transpose each one on every call."""
-    key = (weight.data_ptr(), tuple(weight.shape))
+    bump ``_version``): the decoder has ~40 Linear layers and used to re-cast + re-transpose each one on every call.
+    Keyed on the parameter OBJECT (through a weak reference), never on its address alone: the caching allocator hands a
+    freed parameter's address to the next model's weights."""
+    import weakref
+    base = weight._base if weight._base is not None else weight      # conv.weight.view(out, in) is a fresh view per call
+    key = id(base)
     hit = _W_CACHE.get(key)
-    if hit is None or hit[0] != weight._version:
+    if (hit is None or hit[0]() is not base or hit[1] != base._version or hit[2] != weight.data_ptr()
+            or hit[3].shape != weight.shape):
         if len(_W_CACHE) > 256:
-            _W_CACHE.clear()
-        hit = (weight._version, weight.detach().to(torch.bfloat16).contiguous(), None)
+            for k in [k for k, v in _W_CACHE.items() if v[0]() is None]:
+                del _W_CACHE[k]
+            if len(_W_CACHE) > 256:
+                _W_CACHE.clear()
+        hit = (weakref.ref(base), base._version, weight.data_ptr(), weight.detach().to(torch.bfloat16).contiguous(), None)
         _W_CACHE[key] = hit
-    if want_t and hit[2] is None:
-        hit = (hit[0], hit[1], hit[1].t().contiguous())
+    if want_t and hit[4] is None:
+        hit = hit[:4] + (hit[3].t().contiguous(),)
         _W_CACHE[key] = hit
-    return hit[1], hit[2]
+    return hit[3], hit[4]
 
 
 def _split_scratch(dev):
@@ -101,11 +109,8 @@ class _HipLinearFn(torch.autograd.Function):
         stream = _lib.current_stream_handle()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:   # dX[M,K] = dY[M,N] · W[N,K]: NT form with the K x N transpose of W as "B"
-            hit = _W_CACHE.get((ctx.weight.data_ptr(), tuple(ctx.weight.shape)))
-            if hit is not None and hit[1] is wb:      # still the weight this forward used
-                wt = _cached_bf16(ctx.weight, True)[1]
-            else:
-                wt = wb.t().contiguous()
+            cur, cur_t = _cached_bf16(ctx.weight, True)
+            wt = cur_t if cur is wb else wb.t().contiguous()      # the cached pair only if it is still this forward's weight
             dx = torch.empty(M, K, device=xb.device, dtype=torch.bfloat16)
             _lib.check(lib.sgl_op_gemm_nt(_lib.SGL_DTYPE_BF16, dyb.data_ptr(), N, wt.data_ptr(), N, M, K, N,
                                           _lib.EPI_STORE, dx.data_ptr(), K, None, 0, None, None, 0, None, 0, None, 1, 1,
