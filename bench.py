@@ -263,7 +263,7 @@ def optimizer_step_roofline(pkg, model, x, reps=10):
     e1.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / reps
     n = sum(p.numel() for p in params)
-    return {"kernel": "sgl::grad_sqnorm_kernel + sgl::adamw_kernel (clip_grad_norm_ + AdamW.step, fp32)",
+    return {"kernel": "sgl::grad_sqnorm_kernel + sgl::adamw_ex_kernel (clip_grad_norm_ + AdamW.step, fp32; no shadows attached)",
             "params": n, "ms": round(t * 1e3, 3), "bound": "hbm", "achieved": round(32.0 * n / t / 1e9, 1),
             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(32.0 * n / t / PEAK_HBM, 4)}
 
