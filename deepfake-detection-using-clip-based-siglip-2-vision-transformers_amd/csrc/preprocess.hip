@@ -142,3 +142,75 @@ int sgl_op_preprocess(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Video tail (hidf_video_classifier.py:304-316): per-frame embeddings (B*T, D) -> L2-normalise each frame -> mean over the T
+// frames of a clip -> (B, D).  One workgroup per clip; forward keeps 1/|f| per frame for the backward:
+//   out[b] = (1/T) sum_t f_t / |f_t|          d f_t = (g - fhat_t (fhat_t . g)) / (T |f_t|),  g = d out[b]
+// ---------------------------------------------------------------------------------------------------------------
+namespace sgl {
+
+__global__ __launch_bounds__(256) void l2norm_tmean_fwd_kernel(const float* __restrict__ f, float* __restrict__ out,
+                                                               float* __restrict__ inv_norm, int T, int D) {
+  extern __shared__ float acc[];   // [D]
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) acc[d] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* row = f + ((size_t)b * T + t) * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s += row[d] * row[d];
+    s = wave_sum(s);
+    if (lane_id() == 0) red[wave_id()] = s;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) inv_norm[(size_t)b * T + t] = inv;
+    for (int d = threadIdx.x; d < D; d += 256) acc[d] += row[d] * inv;
+    __syncthreads();
+  }
+  const float it = 1.0f / (float)T;
+  for (int d = threadIdx.x; d < D; d += 256) out[(size_t)b * D + d] = acc[d] * it;
+}
+
+__global__ __launch_bounds__(256) void l2norm_tmean_bwd_kernel(const float* __restrict__ f,
+                                                               const float* __restrict__ inv_norm,
+                                                               const float* __restrict__ dout, float* __restrict__ df,
+                                                               int T, int D) {
+  __shared__ float red[4];
+  const int bt = blockIdx.x, b = bt / T;
+  const float* row = f + (size_t)bt * D;
+  const float* g = dout + (size_t)b * D;
+  const float inv = inv_norm[bt];
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) s += row[d] * g[d];
+  s = wave_sum(s);
+  if (lane_id() == 0) red[wave_id()] = s;
+  __syncthreads();
+  const float dot = ((red[0] + red[1]) + (red[2] + red[3])) * inv;   // fhat . g
+  const float k = inv / (float)T;
+  for (int d = threadIdx.x; d < D; d += 256) df[(size_t)bt * D + d] = (g[d] - row[d] * inv * dot) * k;
+}
+
+}  // namespace sgl
+
+extern "C" {
+
+int sgl_op_l2norm_tmean_fwd(const float* f, float* out, float* inv_norm, int B, int T, int D, sgl_stream stream) {
+  if (!f || !out || !inv_norm) return SGL_ERR_NULL;
+  if (B <= 0 || T <= 0 || D <= 0 || D > 16384) return SGL_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sgl::l2norm_tmean_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)D * sizeof(float),
+                     (hipStream_t)stream, f, out, inv_norm, T, D);
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
+
+int sgl_op_l2norm_tmean_bwd(const float* f, const float* inv_norm, const float* dout, float* df, int B, int T, int D,
+                            sgl_stream stream) {
+  if (!f || !inv_norm || !dout || !df) return SGL_ERR_NULL;
+  if (B <= 0 || T <= 0 || D <= 0) return SGL_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sgl::l2norm_tmean_bwd_kernel, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, f, inv_norm,
+                     dout, df, T, D);
+  return hipGetLastError() == hipSuccess ? SGL_OK : SGL_ERR_HIP;
+}
+
+}  // extern "C"

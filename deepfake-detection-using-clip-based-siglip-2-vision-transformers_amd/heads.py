@@ -493,6 +493,47 @@ class CifakeBinaryHead(nn.Module):
         return f if return_features else self.classifier(f).squeeze(-1)
 
 
+class _L2NormTemporalMeanFn(torch.autograd.Function):
+    """(B*T, D) frame embeddings -> per-frame L2-norm -> mean over the T frames of a clip -> (B, D), one HIP launch forward
+    and one backward (csrc/preprocess.hip) instead of norm / div / view / mean and their four backward kernels
+    (hidf_video_classifier.py:308-316)."""
+
+    @staticmethod
+    def forward(ctx, f, batch_size):
+        from . import lib as _lib
+        lib = _lib.load()
+        f32 = f.float().contiguous()
+        BT, D = f32.shape
+        T = BT // batch_size
+        out = torch.empty(batch_size, D, device=f.device, dtype=torch.float32)
+        inv = torch.empty(BT, device=f.device, dtype=torch.float32)
+        _lib.check(lib.sgl_op_l2norm_tmean_fwd(f32.data_ptr(), out.data_ptr(), inv.data_ptr(), batch_size, T, D,
+                                               _lib.current_stream_handle()), "sgl_op_l2norm_tmean_fwd")
+        ctx.save_for_backward(f32, inv)
+        ctx.dims, ctx.dtype = (batch_size, T, D), f.dtype
+        return out.to(f.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import lib as _lib
+        lib = _lib.load()
+        f32, inv = ctx.saved_tensors
+        B, T, D = ctx.dims
+        g = dout.float().contiguous()
+        df = torch.empty_like(f32)
+        _lib.check(lib.sgl_op_l2norm_tmean_bwd(f32.data_ptr(), inv.data_ptr(), g.data_ptr(), df.data_ptr(), B, T, D,
+                                               _lib.current_stream_handle()), "sgl_op_l2norm_tmean_bwd")
+        return df.to(ctx.dtype), None
+
+
+@torch.compiler.disable
+def l2norm_temporal_mean(frame_features: torch.Tensor, batch_size: int) -> torch.Tensor:
+    """`l2_normalize(f).view(B, T, D).mean(1)`; fused HIP kernels on CUDA tensors, PyTorch ops elsewhere."""
+    if frame_features.is_cuda and frame_features.dim() == 2 and frame_features.shape[0] % batch_size == 0:
+        return _L2NormTemporalMeanFn.apply(frame_features, batch_size)
+    return l2_normalize(frame_features).view(batch_size, -1, frame_features.shape[-1]).mean(dim=1)
+
+
 class VideoBinaryHead(nn.Module):
     """Tail of `BinaryVideoClassifier` (hidf_video_classifier.py:276-320): per-frame L2-norm → mean over T →
     LayerNorm / MLP → one logit per clip.  Input: per-frame embeddings (B*T, D)."""
@@ -507,8 +548,7 @@ class VideoBinaryHead(nn.Module):
             nn.Linear(d // 4, 1))
 
     def forward(self, frame_features, batch_size: int):
-        f = l2_normalize(frame_features).view(batch_size, -1, frame_features.shape[-1])
-        return self.binary_classifier(f.mean(dim=1)).squeeze(-1)
+        return self.binary_classifier(l2norm_temporal_mean(frame_features, batch_size)).squeeze(-1)
 
 
 class SEBinaryHead(nn.Module):

@@ -239,6 +239,13 @@ int sgl_op_preprocess(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws
                       int Kp, int patch_major, float mean, float std, const int* mix_index, float lam,
                       sgl_stream stream);
 
+/* Video tail (hidf_video_classifier.py:304-316): per-frame embeddings f (B*T, D) fp32 -> each frame L2-normalised ->
+ * mean over the T frames of a clip -> out (B, D); inv_norm (B*T) keeps 1/|f_t| for the backward
+ * d f_t = (g - fhat_t (fhat_t . g)) / (T |f_t|), g = d out[b]. */
+int sgl_op_l2norm_tmean_fwd(const float* f, float* out, float* inv_norm, int B, int T, int D, sgl_stream stream);
+int sgl_op_l2norm_tmean_bwd(const float* f, const float* inv_norm, const float* dout, float* df, int B, int T, int D,
+                            sgl_stream stream);
+
 /* ---- SID mask-decoder tail, second half (Siglip2sidafrozen.py:731-745,174-181) -------------------
  * y = sigmoid(g) * x on n elements (the channel gate applied to the concatenated taps, `gate * x` at :741-742), and its
  * backward: dx = dy * sigmoid(g), dg = dy * x * s(1-s) (gradient w.r.t. the PRE-sigmoid gate; dg / dx may be NULL).

@@ -85,3 +85,20 @@ def test_training_loss_equals_forward_then_mtl_loss(pkg, hiplib):
         if n in want and not (n.endswith("k_proj.bias") or n.endswith("in_proj_bias")):   # exactly-zero gradients: noise
             err = (p.grad - want[n]).abs().max().item() / (want[n].abs().max().item() + 1e-30)
             assert err < 5e-5, (n, err)
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 32, 1152), (3, 4, 64), (1, 1, 768), (5, 7, 100)])
+def test_video_l2norm_temporal_mean_forward_backward(pkg, hiplib, B, T, D):
+    """heads.l2norm_temporal_mean (one HIP launch each way) against the reference's composition
+    f / f.norm(dim=-1, keepdim=True) -> view(B, T, D) -> mean(1)  (hidf_video_classifier.py:308-316)."""
+    H = pkg.heads
+    torch.manual_seed(B * 10 + T)
+    f = (torch.randn(B * T, D, device="cuda") * 3).requires_grad_(True)
+    g = torch.randn(B, D, device="cuda")
+    out = H.l2norm_temporal_mean(f, B)
+    out.backward(g)
+    fr = f.detach().clone().requires_grad_(True)
+    ref = (fr / fr.norm(dim=-1, keepdim=True)).view(B, T, D).mean(1)
+    ref.backward(g)
+    assert (out - ref).abs().max().item() < 2e-6
+    assert (f.grad - fr.grad).abs().max().item() <= 2e-6 * max(1.0, fr.grad.abs().max().item())
