@@ -59,7 +59,24 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Workgroup -> (head, 128-row block of that head).  The dispatcher deals workgroups to the 8 XCDs round-robin in linear-id
+// order, and every XCD has its own L2: with the natural (block, head) grid the `nb` workgroups of one head — which all
+// stream the SAME Q/dO (or K/V) tiles of that head — sat on `nb` different XCDs, so every tile was an L2 miss `nb` times
+// over.  Here XCD x owns heads x, x+8, x+16, ... and runs their `nb` blocks back to back: one miss, nb-1 L2 hits.
+// 1-D launch of 8 * ceil(BH / 8) * nb workgroups (head_grid); workgroups of the padding heads exit at once.
+__device__ __forceinline__ bool head_block(int nb, int BH, int& bh, int& xb) {
+  const int pid = blockIdx.x, xcd = pid & 7, slot = pid >> 3;
+  const int hq = slot / nb;
+  bh = hq * 8 + xcd;
+  xb = slot - hq * nb;
+  return bh < BH;
+}
+static inline dim3 head_grid(int nb, int BH) { return dim3((unsigned)(8 * ((BH + 7) / 8) * nb)); }
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#ifndef SGL_ATTN_DBG
+#define SGL_ATTN_DBG 0   // developer ablations of the kv kernel (timing only, results wrong): see tests/bench_attn.py
+#endif
 
 // ======================================================================================================
 // forward
@@ -67,7 +84,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 template <int DP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ out,
-                                                          float* __restrict__ lse, int H, int N, int dh, float c,
+                                                          float* __restrict__ lse, int B, int H, int N, int dh, float c,
                                                           float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 64;
@@ -75,8 +92,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   constexpr int NCH = KT * C::CPR, NQ = (NCH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  int bh, xb;
+  if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
+  const int b = bh / H, hd = bh - b * H;
+  const int q0 = xb * 128 + w * 32;
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
@@ -260,9 +279,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+  int bh, xb;
+  if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
+  const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
-  const int key0 = blockIdx.x * 128 + w * 32;
+  const int key0 = xb * 128 + w * 32;
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
@@ -296,8 +317,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     }
     if (t < QT) {
       const int qrow = qt * QT + t;
-      s_l = (qrow < N) ? lse[(size_t)bh * N + qrow] * LOG2E : INFINITY;
-      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] * scale : 0.f;   // pre-scaled: dS = p * fma(dP, scale, -delta*scale)
+      // raw values only: any arithmetic on them here would make the compiler wait for the whole tile's loads (vmcnt is
+      // in-order) at the START of the tile — it did, on wave 0, with the other three waiting at the barrier
+      s_l = (qrow < N) ? lse[(size_t)bh * N + qrow] : INFINITY;
+      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] : 0.f;
     }
   };
   auto store_stage = [&](int stage) {
@@ -312,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
       }
     }
     if (t < QT) {
-      reinterpret_cast<float*>(base + 2 * IMG)[t] = s_l;
-      reinterpret_cast<float*>(base + 2 * IMG + QT * 4)[t] = s_d;
+      reinterpret_cast<float*>(base + 2 * IMG)[t] = s_l * LOG2E;
+      reinterpret_cast<float*>(base + 2 * IMG + QT * 4)[t] = s_d * scale;   // pre-scaled: dS = p * fma(dP, scale, -delta*scale)
     }
   };
 
@@ -328,9 +351,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   __syncthreads();
   store_stage(0);
   __syncthreads();
+  // retire the K/V fragment loads HERE, unconditionally: otherwise the waitcnt pass carries them into the loop as "maybe
+  // pending" and guards phase A's MFMAs with vmcnt(N) waits that, in steady state, wait on the tile prefetch just issued
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(kfr[ks]), "v"(vfr[ks]));
+  constexpr int DBG = SGL_ATTN_DBG;
   for (int qt = 0; qt < ntiles; ++qt) {
     const int cur = qt & 1;
-    if (qt + 1 < ntiles) load_tile(qt + 1);
+    if (!(DBG & (4 | 64)) && qt + 1 < ntiles) load_tile(qt + 1);
     const char* qimg = smem + cur * STAGE;
     const char* dimg = qimg + IMG;
     const float* lrow = reinterpret_cast<const float*>(qimg + 2 * IMG);
@@ -344,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     bf16x8 qa[C::KS], da[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
+      if constexpr (DBG & 16) { qa[ks] = kfr[(ks + 1) % C::KS]; da[ks] = vfr[(ks + 1) % C::KS]; continue; }
       qa[ks] = lds_row8(qimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
       da[ks] = lds_row8(dimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
     }
@@ -352,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
       S = MFMA32(qa[ks], kfr[ks], S);
       dP = MFMA32(da[ks], vfr[ks], dP);
     }
-    if constexpr (C::KS == 5) {   // 4 fragments in flight ahead of the MFMA chain
+    if constexpr (C::KS == 5 && !(DBG & 16)) {   // 4 fragments in flight ahead of the MFMA chain
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -368,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     bf16x8 fr[NF];
     auto frag = [&](int i) {
       const int which = i & 1, kk = (i >> 1) & 1, dt = i >> 2;
+      if constexpr (DBG & 2) return which ? kfr[i % C::KS] : vfr[i % C::KS];
       return lds_trfrag(which ? qimg : dimg, C::DSTR, kk, dt * 32, lane);
     };
     constexpr int PRE = NF < 2 ? NF : 2;
@@ -382,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
 #pragma unroll
       for (int r3 = 0; r3 < 4; ++r3) {
         const int r = 4 * g4 + r3;
+        if constexpr (DBG & 1) { dP[r] = S[r] * dP[r] + L4[r3] * D4[r3]; continue; }
         const float p = fast_exp2(fmaf(S[r], c, -L4[r3]));
         S[r] = p;
         dP[r] = p * fmaf(dP[r], scale, -D4[r3]);
@@ -401,14 +432,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
       if (which) dk[dt] = MFMA32(fr[i], dsb[kk], dk[dt]);
       else dv[dt] = MFMA32(fr[i], pb[kk], dv[dt]);
     }
+    if constexpr (!(DBG & 2)) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i + PRE < NF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      for (int i = 0; i < NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + PRE < NF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (qt + 1 < ntiles) store_stage(cur ^ 1);
-    __syncthreads();
+    if (!(DBG & (4 | 32)) && qt + 1 < ntiles) store_stage(cur ^ 1);
+    if constexpr (DBG & 32) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(sq[q]), "v"(sd[q]), "v"(s_l), "v"(s_d));
+    }
+    if constexpr (!(DBG & 8)) __syncthreads();
   }
   const int key = key0 + li;
   if (key < N) {
@@ -449,9 +486,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+  int bh, xb;
+  if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
+  const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q0 = xb * 128 + w * 32;
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
@@ -595,8 +634,8 @@ static hipError_t fwd_launch(const bf16* q, const bf16* k, const bf16* v, bf16* 
   using C = AttnCfg<DP>;
   constexpr int smem = 2 * (64 * C::RSTR + 64 * C::TSTR);
   const float scale = 1.0f / sqrtf((float)dh);
-  hipLaunchKernelGGL(attn_fwd_kernel<DP>, dim3((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse, H, N, dh,
-                     scale * 1.4426950408889634f, scale);
+  hipLaunchKernelGGL(attn_fwd_kernel<DP>, head_grid((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse, B, H, N,
+                     dh, scale * 1.4426950408889634f, scale);
   return hipGetLastError();
 }
 
@@ -613,7 +652,7 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   if (e != hipSuccess) return e;
   constexpr int smem_kv = 2 * (2 * 32 * C::DSTR + 2 * 32 * 4);
   constexpr int smem_q = 2 * (32 * C::DSTR + 32 * C::RSTR);
-  dim3 grid((N + 127) / 128, B * H), block(256);
+  const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
   hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, lse, delta, dqkv, B, H, N, dh, c,
                      scale);
   e = hipGetLastError();
