@@ -187,7 +187,7 @@ def step_breakdown(pkg, cfg, batch, res, reps, nt_per_shape):
     o = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
     do = torch.randn(M, D, device=dev).bfloat16()
     lse = torch.empty(batch, Hh, Ntok, device=dev)
-    delta = torch.empty(batch, Hh, Ntok, device=dev)
+    delta = torch.empty(2, batch, Hh, Ntok, device=dev)
     dqkv = torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16)
     fam["attn_fwd"] = timeit(lambda: lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(),
                                                          o.data_ptr(), lse.data_ptr(), batch, Hh, Ntok, dh, DP,

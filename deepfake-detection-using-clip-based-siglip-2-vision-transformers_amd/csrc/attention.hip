@@ -9,7 +9,7 @@
 // the row max / row sum are lane-local plus one cross-half shuffle, the running rescale factor is a per-lane
 // scalar, and Oᵀ = Vᵀ·Pᵀ consumes the Sᵀ accumulator registers directly as the MFMA B operand (no LDS round
 // trip for P).  Vᵀ fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16.
-// Backward recomputes P from the saved log-sum-exp.  Two kernels, no atomics, bitwise reproducible:
+// Backward recomputes P from the saved log-sum-exp.  Two kernels (after the delta pre-pass), no atomics, bitwise reproducible:
 //   kv-kernel ("key on the lane"):  S = Q·Kᵀ, dP = dO·Vᵀ, dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS   (wave owns 32 keys)
 //   q-kernel  ("query on the lane"): Sᵀ = K·Qᵀ, dPᵀ = V·dOᵀ, dQᵀ += Kᵀ·dSᵀ             (wave owns 32 queries)
 //
@@ -74,9 +74,6 @@ __device__ __forceinline__ bool head_block(int nb, int BH, int& bh, int& xb) {
 static inline dim3 head_grid(int nb, int BH) { return dim3((unsigned)(8 * ((BH + 7) / 8) * nb)); }
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-#ifndef SGL_ATTN_DBG
-#define SGL_ATTN_DBG 0   // developer ablations of the kv kernel (timing only, results wrong): see tests/bench_attn.py
-#endif
 
 // ======================================================================================================
 // forward
@@ -231,8 +228,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ======================================================================================================
 // One wave per token row: 16-byte coalesced loads of the whole [H*dh] row, per-chunk partial sums, then a
 // segmented sum of the dh/8 chunks of each head.  HBM-bound: 2 * D * 2 bytes per token.
+// Output aux[b][h][n] = {-lse * log2(e), -delta * scale}: the addends of the two backward kernels' fused multiply-adds
+// (p = exp2(S*c + aux.x), dS = p * (dP*scale + aux.y)).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO,
-                                                         float* __restrict__ delta, int B, int H, int N, int dh) {
+                                                         const float* __restrict__ lse, float* __restrict__ aux, int B, int H,
+                                                         int N, int dh, float scale) {
   __shared__ float part[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const size_t tok = (size_t)blockIdx.x * 4 + w;
@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
     for (int h = lane; h < H; h += 64) {
       float acc = 0.f;
       for (int c = 0; c < cph; ++c) acc += part[w][h * cph + c];
-      delta[((size_t)b * H + h) * N + i] = acc;
+      // the two per-query constants of the backward, pre-scaled for the kernels' exp2 / dS forms, as one 8-byte pair
+      const size_t idx = ((size_t)b * H + h) * N + i;
+      *reinterpret_cast<float2*>(aux + 2 * idx) = make_float2(-lse[idx] * 1.4426950408889634f, -acc * scale);
     }
   }
 }
@@ -265,20 +267,56 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // ======================================================================================================
 // backward: dK, dV   (wave owns 32 keys; sweeps 32-query tiles staged in LDS)
 // ======================================================================================================
+// Staging (this kernel and the dQ kernel): global -> LDS by DMA (buffer_load ... lds, 16 B per lane, 1 KiB per instruction),
+// three LDS stages, tile t+2 requested while tile t is computed.  One raw s_barrier per tile; no staging registers, no
+// ds_write, no address arithmetic in the loop beyond one add per DMA instruction.  The register-staged version it
+// replaces (load tile t+1 at the top, ds_write + barrier at the bottom) cost 24 % of the kernel: an ablation without the
+// staging ran 134 us faster of 560 (B = 64), half of it the ds_write -> lgkmcnt(0) -> barrier chain at the end of every tile.
+// An image row holds `SC` 16-byte chunks of which the first `NC` are data; DMA lanes of the pad chunks (and of rows past N)
+// point out of range and write zeros, so the pad columns the 80 -> 96 wide transposed reads touch are always clean.
+// The DMA goes through inline asm (see gemm_bf16_v2.hip): the kernel owns the vmcnt accounting for it.
+__device__ __forceinline__ void att_dma16(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
+               : "memory");
+}
+__device__ __forceinline__ void att_dma4(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
+               : "memory");
+}
+__device__ __forceinline__ u32x4 att_desc(const void* base, uint32_t bytes) {
+  const uint64_t q = (uint64_t)base;
+  return u32x4{(uint32_t)q, (uint32_t)(q >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+// global byte offset (tile 0) of image chunk `cidx` for a row-major source with `rowbytes` per row
+__device__ __forceinline__ uint32_t att_chunk_off(int cidx, int rows, int SC, int NC, uint32_t rowbytes) {
+  const int row = cidx / SC, col = cidx - row * SC;
+  return (row < rows && col < NC) ? (uint32_t)row * rowbytes + (uint32_t)col * 16u : SGL_OOB;
+}
+#define SGL_ATT_WAIT_BARRIER(n)                                   \
+  do {                                                            \
+    asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    __builtin_amdgcn_s_barrier();                                 \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    asm volatile("" ::: "memory");                                \
+  } while (0)
+
 template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                              const bf16* __restrict__ V, const bf16* __restrict__ dO,
-                                                             const float* __restrict__ lse,
-                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                             const float* __restrict__ aux, bf16* __restrict__ dqkv,
                                                              int B, int H, int N, int dh, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int QT = 32;
-  constexpr int IMG = QT * C::DSTR;            // one dual-use image
-  constexpr int STAGE = 2 * IMG + 2 * QT * 4;  // Q image, dO image, lse[32], delta[32]
-  constexpr int NCH = QT * C::CPR, NQ = (NCH + 255) / 256;
-  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int SC = C::DSTR / 16;                         // chunks per image row (13)
+  constexpr int NIS = (QT * SC + 63) / 64;                 // DMA instructions per image (7)
+  constexpr int IMG = NIS * 1024;                          // one dual-use image incl. slack
+  constexpr int STAGE = 2 * IMG + QT * 8;                  // Q image, dO image, {-lse*log2e, -delta*scale}[32]
+  constexpr int NSLOT = 2 * NIS + 1;                       // DMA instructions per tile, dealt to the 4 waves round-robin
+  static_assert(NSLOT <= 16 && NSLOT > 12, "four DMA slots per wave (three for the last wave)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   int bh, xb;
   if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
   const int b = bh / H, hd = bh - b * H;
@@ -286,13 +324,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   const int key0 = xb * 128 + w * 32;
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
   const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
   const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
-  const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
-
-  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+  const u32x4 dq_ = att_desc(Q + mat, mbytes);
+  const u32x4 ddo = att_desc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
+  const u32x4 dax = att_desc(aux + (size_t)bh * N * 2, (uint32_t)((size_t)N * 8));
+  const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
 
   const int li = lane & 31, hh = lane >> 5;
   bf16x8 kfr[C::KS], vfr[C::KS];
@@ -303,41 +341,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     vfr[ks] = as_bf16x8(a_ldg(rv, off));
   }
 
-  u32x4 sq[NQ], sd[NQ];
-  float s_l = 0.f, s_d = 0.f;
-  auto load_tile = [&](int qt) {
+  // this wave's DMA slots: sl = w + 4j.  sl < NIS: Q image, sl < 2*NIS: dO image, sl == 2*NIS: the 32 {lse, delta} pairs.
+  // Slots j = 0..2 are 16-byte image slots for every wave (straight-line code, descriptor picked once); j = 3 is an image
+  // slot for waves 0-1, the pair slot for wave 2 and nothing for wave 3.  Tiles are requested in order, so the per-lane
+  // offsets just advance by one tile per issue().
+  uint32_t voff[4], vadv[4];
+  u32x4 dsc[3];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ch = t + q * 256;
-      const int row = ch / C::CPR, cc = ch - row * C::CPR;
-      const int qrow = qt * QT + row;
-      const bool ok = (ch < NCH) && (qrow < N);
-      sq[q] = a_ldg(rq, ok ? (uint32_t)((qrow * DP + cc * 8) * 2) : SGL_OOB);
-      sd[q] = a_ldg(rdo, (ok && cc * 8 < dh) ? (uint32_t)(((size_t)qrow * D + cc * 8) * 2) : SGL_OOB);
+  for (int j = 0; j < 4; ++j) {
+    const int sl = w + 4 * j;
+    if (sl < NIS) {
+      voff[j] = att_chunk_off(sl * 64 + lane, QT, SC, DP / 8, (uint32_t)DP * 2u);
+      vadv[j] = (uint32_t)(QT * DP * 2);
+    } else if (sl < 2 * NIS) {
+      voff[j] = att_chunk_off((sl - NIS) * 64 + lane, QT, SC, dh / 8, (uint32_t)D * 2u);
+      vadv[j] = (uint32_t)(QT * D * 2);
+    } else {
+      voff[j] = (uint32_t)lane * 4u;
+      vadv[j] = (uint32_t)(QT * 8);
     }
-    if (t < QT) {
-      const int qrow = qt * QT + t;
-      // raw values only: any arithmetic on them here would make the compiler wait for the whole tile's loads (vmcnt is
-      // in-order) at the START of the tile — it did, on wave 0, with the other three waiting at the barrier
-      s_l = (qrow < N) ? lse[(size_t)bh * N + qrow] : INFINITY;
-      s_d = (qrow < N) ? delta[(size_t)bh * N + qrow] : 0.f;
+    if (j < 3) dsc[j] = (sl < NIS) ? dq_ : ddo;
+  }
+  // one DMA instruction of this wave (j = 0..3) into `stage`; tiles past the end read out of range (zeros into a stage
+  // nobody reads again), so the loop issues unconditionally and its vmcnt accounting is the same for every tile
+  auto issue1 = [&](int j, int stage) {
+    const uint32_t sb = lds0 + (uint32_t)(stage * STAGE) + (uint32_t)w * 1024u;
+    if (j < 3) {
+      att_dma16(dsc[j], sb + (uint32_t)j * 4096u, voff[j]);   // out-of-range lanes stay >= 2^31 as they advance
+    } else {
+      if (w < 2) att_dma16(ddo, sb + 3u * 4096u, voff[3]);
+      else if (w == 2) att_dma4(dax, lds0 + (uint32_t)(stage * STAGE + 2 * IMG), voff[3]);
     }
+    voff[j] += vadv[j];
   };
-  auto store_stage = [&](int stage) {
-    char* base = smem + stage * STAGE;
+  auto issue = [&](int stage) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ch = t + q * 256;
-      if (ch < NCH) {
-        const int row = ch / C::CPR, cc = ch - row * C::CPR;
-        *reinterpret_cast<u32x4*>(base + row * C::DSTR + cc * 16) = sq[q];
-        *reinterpret_cast<u32x4*>(base + IMG + row * C::DSTR + cc * 16) = sd[q];
-      }
-    }
-    if (t < QT) {
-      reinterpret_cast<float*>(base + 2 * IMG)[t] = s_l * LOG2E;
-      reinterpret_cast<float*>(base + 2 * IMG + QT * 4)[t] = s_d * scale;   // pre-scaled: dS = p * fma(dP, scale, -delta*scale)
-    }
+    for (int j = 0; j < 4; ++j) issue1(j, stage);
   };
 
   f32x16 dk[C::DT], dv[C::DT];
@@ -347,32 +386,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
   const int ntiles = (N + QT - 1) / QT;
-  load_tile(0);
-  __syncthreads();
-  store_stage(0);
-  __syncthreads();
-  // retire the K/V fragment loads HERE, unconditionally: otherwise the waitcnt pass carries them into the loop as "maybe
-  // pending" and guards phase A's MFMAs with vmcnt(N) waits that, in steady state, wait on the tile prefetch just issued
+  // retire the K/V fragment loads before the first DMA: the compiler's own vmcnt bookkeeping does not see the DMA
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(kfr[ks]), "v"(vfr[ks]));
-  constexpr int DBG = SGL_ATTN_DBG;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue(0);
+  issue(1);
+  int st = 0;                                  // stage of tile qt
   for (int qt = 0; qt < ntiles; ++qt) {
-    const int cur = qt & 1;
-    if (!(DBG & (4 | 64)) && qt + 1 < ntiles) load_tile(qt + 1);
-    const char* qimg = smem + cur * STAGE;
+    // tile qt has landed (own DMA: all but the younger tile's instructions; everyone's: barrier) and every wave is done
+    // reading the stage tile qt+2 will overwrite
+    if (w == 3) SGL_ATT_WAIT_BARRIER(3); else SGL_ATT_WAIT_BARRIER(4);
+    const int st_next = (st == 0) ? 2 : st - 1;   // stage of tile qt+2 (= of tile qt-1)
+    const char* qimg = smem + st * STAGE;
     const char* dimg = qimg + IMG;
-    const float* lrow = reinterpret_cast<const float*>(qimg + 2 * IMG);
-    const float* drow = lrow + QT;
+    const float* ld = reinterpret_cast<const float*>(qimg + 2 * IMG);
+    st = (st == 2) ? 0 : st + 1;
     f32x16 S, dP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
-    // ---- phase A: S = Q·Kᵀ, dP = dO·Vᵀ.  All row fragments and the tile's lse / delta rows are requested up front and
-    // the schedule is pinned (sched_group_barrier): left alone, hipcc issued two LDS reads and waited for them in front of
-    // EVERY MFMA, so the matrix pipe idled for an LDS round trip 22 times per tile (PMC: waves parked 43 % of the time).
+    // ---- phase A: S = Q·Kᵀ, dP = dO·Vᵀ.  All row fragments are requested up front and the schedule is pinned
+    // (sched_group_barrier): left alone, hipcc issued two LDS reads and waited for them in front of EVERY MFMA, so the
+    // matrix pipe idled for an LDS round trip 22 times per tile (PMC: waves parked 43 % of the time).
     bf16x8 qa[C::KS], da[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      if constexpr (DBG & 16) { qa[ks] = kfr[(ks + 1) % C::KS]; da[ks] = vfr[(ks + 1) % C::KS]; continue; }
       qa[ks] = lds_row8(qimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
       da[ks] = lds_row8(dimg + li * C::DSTR + (16 * ks + 8 * hh) * 2);
     }
@@ -381,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
       S = MFMA32(qa[ks], kfr[ks], S);
       dP = MFMA32(da[ks], vfr[ks], dP);
     }
-    if constexpr (C::KS == 5 && !(DBG & 16)) {   // 4 fragments in flight ahead of the MFMA chain
+    if constexpr (C::KS == 5) {   // 4 fragments in flight ahead of the MFMA chain
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -397,25 +435,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     bf16x8 fr[NF];
     auto frag = [&](int i) {
       const int which = i & 1, kk = (i >> 1) & 1, dt = i >> 2;
-      if constexpr (DBG & 2) return which ? kfr[i % C::KS] : vfr[i % C::KS];
       return lds_trfrag(which ? qimg : dimg, C::DSTR, kk, dt * 32, lane);
     };
     constexpr int PRE = NF < 2 ? NF : 2;
 #pragma unroll
     for (int i = 0; i < PRE; ++i) fr[i] = frag(i);
     __builtin_amdgcn_sched_barrier(0);
-    // S[r], dP[r]: query row (r&3) + 8*(r>>2) + 4*hh of the tile, key = lane & 31
+    // S[r], dP[r]: query row (r&3) + 8*(r>>2) + 4*hh of the tile, key = lane & 31;  ld[2*row] = -lse*log2e, ld[2*row+1] =
+    // -delta*scale (delta kernel): p = exp2(S*c - lse*log2e), dS = p * (dP*scale - delta*scale)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 L4 = *reinterpret_cast<const f32x4*>(lrow + 8 * g4 + 4 * hh);
-      const f32x4 D4 = *reinterpret_cast<const f32x4*>(drow + 8 * g4 + 4 * hh);
+      const f32x4 A0 = *reinterpret_cast<const f32x4*>(ld + 2 * (8 * g4 + 4 * hh));
+      const f32x4 A1 = *reinterpret_cast<const f32x4*>(ld + 2 * (8 * g4 + 4 * hh) + 4);
+      const float L4[4] = {A0[0], A0[2], A1[0], A1[2]};
+      const float D4[4] = {A0[1], A0[3], A1[1], A1[3]};
 #pragma unroll
       for (int r3 = 0; r3 < 4; ++r3) {
         const int r = 4 * g4 + r3;
-        if constexpr (DBG & 1) { dP[r] = S[r] * dP[r] + L4[r3] * D4[r3]; continue; }
-        const float p = fast_exp2(fmaf(S[r], c, -L4[r3]));
+        const float p = fast_exp2(fmaf(S[r], c, L4[r3]));
         S[r] = p;
-        dP[r] = p * fmaf(dP[r], scale, -D4[r3]);
+        dP[r] = p * fmaf(dP[r], scale, D4[r3]);
       }
     }
     bf16x8 pb[2], dsb[2];
@@ -431,22 +470,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
       const int which = i & 1, kk = (i >> 1) & 1, dt = i >> 2;
       if (which) dk[dt] = MFMA32(fr[i], dsb[kk], dk[dt]);
       else dv[dt] = MFMA32(fr[i], pb[kk], dv[dt]);
+      // the request for tile qt+2, one DMA instruction behind every third MFMA: the texture addresser takes ~16 cycles per
+      // 64-lane 16-byte instruction and a wave that cannot hand its instruction over stalls IN ORDER — issued as a burst
+      // after the barrier, four waves' sixteen instructions held every wave's phase A back (15 % of the kernel); here
+      // the hand-over runs under the matrix pipe's 32 cycles
+      if (i % 3 == 1) issue1(i / 3, st_next);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!(DBG & 2)) {
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i + PRE < NF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & (4 | 32)) && qt + 1 < ntiles) store_stage(cur ^ 1);
-    if constexpr (DBG & 32) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(sq[q]), "v"(sd[q]), "v"(s_l), "v"(s_d));
-    }
-    if constexpr (!(DBG & 8)) __syncthreads();
+    for (int j = (NF + 1) / 3; j < 4; ++j) issue1(j, st_next);   // head dims with fewer than 11 MFMAs in phase B
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing out-of-range requests
   const int key = key0 + li;
   if (key < N) {
     bf16* krow = dqkv + ((size_t)b * N + key) * (3 * (size_t)D) + D + hd * dh;
@@ -476,8 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
 template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, const bf16* __restrict__ dO,
-                                                            const float* __restrict__ lse,
-                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                            const float* __restrict__ aux, bf16* __restrict__ dqkv,
                                                             int B, int H, int N, int dh, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 32;
@@ -510,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     qf[ks] = as_bf16x8(a_ldg(rq, (q < N) ? (uint32_t)((q * DP + col) * 2) : SGL_OOB));
     dof[ks] = as_bf16x8(a_ldg(rdo, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
   }
-  const float Lq = (q < N) ? lse[(size_t)bh * N + q] * LOG2E : INFINITY;
-  const float Dq = (q < N) ? delta[(size_t)bh * N + q] * scale : 0.f;   // pre-scaled (see the kv kernel)
+  const float2 ax = (q < N) ? *reinterpret_cast<const float2*>(aux + 2 * ((size_t)bh * N + q)) : make_float2(-INFINITY, 0.f);
+  const float Lq = ax.x, Dq = ax.y;   // -lse*log2e, -delta*scale (delta kernel)
 
   u32x4 sk[NQ], sv[NQ];
   auto load_tile = [&](int kt) {
@@ -588,8 +621,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = fast_exp2(fmaf(S[r], c, -Lq));
-      dP[r] = p * fmaf(dP[r], scale, -Dq);
+      const float p = fast_exp2(fmaf(S[r], c, Lq));
+      dP[r] = p * fmaf(dP[r], scale, Dq);
     }
     if (kt == ntiles - 1) {   // keys past N exist only in the last tile (wave-uniform branch: 4 VALU per score saved elsewhere)
 #pragma unroll
@@ -646,19 +679,17 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   const float scale = 1.0f / sqrtf((float)dh);
   const float c = scale * 1.4426950408889634f;
   const size_t ntok = (size_t)B * N;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, out, dout, delta, B, H, N,
-                     dh);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, out, dout, lse, delta, B, H, N,
+                     dh, scale);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  constexpr int smem_kv = 2 * (2 * 32 * C::DSTR + 2 * 32 * 4);
+  constexpr int smem_kv = 3 * (2 * ((32 * (C::DSTR / 16) + 63) / 64) * 1024 + 32 * 8);
   constexpr int smem_q = 2 * (32 * C::DSTR + 32 * C::RSTR);
   const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, lse, delta, dqkv, B, H, N, dh, c,
-                     scale);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, dout, lse, delta, dqkv, B, H, N, dh, c,
-                     scale);
+  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
   return hipGetLastError();
 }
 

@@ -117,7 +117,7 @@ struct Layout {
       w_du = w.take(Mz * Ip * es);
       w_dh = w.take(Mz * D * es);
       w_dqkv = w.take(Mz * 3 * D * es);
-      w_delta = w.take((size_t)B * c->H * N * 4);
+      w_delta = w.take((size_t)B * c->H * N * 8);   // {lse*log2e, delta*scale} pairs
       w_splitws = w.take(kSplitWsBytes);  // private slabs of the split-K dW GEMMs (deterministic reduction)
       w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 3 * D * 4);
       w_gsum = w.take(D * 4);        // column sums of the current d hidden_states (bias grad of the GEMM below)

@@ -106,7 +106,7 @@ hipError_t gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, int Mred
 // q,k,v: head-major [B][H][N][DP]; out: token-major [B*N][H*dh]; lse: [B][H][N] (natural log units)
 hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void* out, float* lse, int B, int H,
                     int N, int dh, int DP, hipStream_t s);
-// dout: token-major [B*N][H*dh] (T); dqkv: token-major [B*N][3*H*dh] (T); delta: [B][H][N] scratch
+// dout: token-major [B*N][H*dh] (T); dqkv: token-major [B*N][3*H*dh] (T); delta: scratch of 2*B*H*N floats
 hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, int dtype, void* dqkv, float* delta, float* reserved, int B, int H, int N,
                     int dh, int DP, hipStream_t s);

@@ -201,6 +201,7 @@ int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb,
                       float* out, int ldo, int accumulate, float* scratch, size_t scratch_bytes, sgl_stream stream);
 int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
                     int head_dim, int head_dim_pad, sgl_stream stream);
+/* delta_scratch: 2 * B * H * N floats (per query and head the pair {-lse * log2 e, -rowsum(dO * O) / sqrt(head_dim)}). */
 int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, void* dqkv, float* delta_scratch, int B, int H, int N, int head_dim,
                     int head_dim_pad, sgl_stream stream);

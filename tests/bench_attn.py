@@ -13,7 +13,7 @@ qkv = torch.zeros(3, B, H, N, DP, device="cuda", dtype=torch.bfloat16)
 qkv[..., :dh] = torch.randn(3, B, H, N, dh, device="cuda").bfloat16()
 out = torch.empty(B * N, D, device="cuda", dtype=torch.bfloat16)
 dout = torch.randn(B * N, D, device="cuda").bfloat16()
-lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty(B, H, N, device="cuda")
+lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty(2, B, H, N, device="cuda")
 dqkv = torch.empty(B * N, 3 * D, device="cuda", dtype=torch.bfloat16)
 def fwd(): assert lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, N, dh, DP, st.cuda_stream) == 0
 def bwd(): assert lib.sgl_op_attn_bwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), B, H, N, dh, DP, st.cuda_stream) == 0

@@ -42,7 +42,7 @@ __device__ __forceinline__ void body(float (&v)[16], f32x2 (&p)[16], unsigned (&
 }
 
 template <int TA, int TB>
-__global__ __launch_bounds__(512) void k(long long* cyc, float* out, int iters) {
+__global__ __launch_bounds__(512) void k(long long* cyc, float* out, int iters, int noisy) {
   const int w = threadIdx.x >> 6;
   float v[16];
   f32x2 p[16];
@@ -50,6 +50,13 @@ __global__ __launch_bounds__(512) void k(long long* cyc, float* out, int iters) 
   f32x16 acc[4];
   bf16x8 x, y;
   for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(float)(threadIdx.x & 3); y[i] = (__bf16)0.5f; }
+  if (noisy) {   // operands with random mantissas / signs: realistic toggle rate for the power question
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = 0; i < 8; ++i) {
+      h = h * 1664525u + 1013904223u; x[i] = (__bf16)(((int)(h >> 9) & 0xffff) * (1.0f / 32768.f) - 1.0f);
+      h = h * 1664525u + 1013904223u; y[i] = (__bf16)(((int)(h >> 9) & 0xffff) * (1.0f / 32768.f) - 1.0f);
+    }
+  }
   for (int i = 0; i < 16; ++i) { v[i] = 0.001f * (threadIdx.x + i); p[i] = f32x2{v[i], -v[i]}; u[i] = 0; }
   for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
   const float ca = 0.999f, cb = 1e-3f;
@@ -67,17 +74,17 @@ __global__ __launch_bounds__(512) void k(long long* cyc, float* out, int iters) 
   if ((threadIdx.x & 63) == 0 && blockIdx.x == gridDim.x - 1) cyc[w] = t1 - t0;
 }
 
-static long long* d_cyc; static float* d_out; static int g_grid = 1;
+static long long* d_cyc; static float* d_out; static int g_grid = 1; static int g_noisy = 0;
 template <int TA, int TB>
 static void run(const char* name, double instrs_a, double instrs_b) {
   const int iters = 20000;
   long long h[8];
   static hipEvent_t e0, e1;
   if (!e0) { hipEventCreate(&e0); hipEventCreate(&e1); }
-  hipLaunchKernelGGL((k<TA, TB>), dim3(g_grid), dim3(512), 0, 0, d_cyc, d_out, iters);
+  hipLaunchKernelGGL((k<TA, TB>), dim3(g_grid), dim3(512), 0, 0, d_cyc, d_out, iters, g_noisy);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<TA, TB>), dim3(g_grid), dim3(512), 0, 0, d_cyc, d_out, iters);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<TA, TB>), dim3(g_grid), dim3(512), 0, 0, d_cyc, d_out, iters, g_noisy);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -96,8 +103,9 @@ static void run(const char* name, double instrs_a, double instrs_b) {
 
 int main(int argc, char** argv) {
   if (argc > 1) g_grid = atoi(argv[1]);
+  if (argc > 2) g_noisy = atoi(argv[2]);
   hipMalloc(&d_cyc, 64); hipMalloc(&d_out, (size_t)g_grid * 512 * 4);
-  printf("grid = %d workgroups of 8 waves\n", g_grid);
+  printf("grid = %d workgroups of 8 waves, %s MFMA operands\n", g_grid, g_noisy ? "random" : "constant");
   printf("-- one wave per SIMD, solo --\n");
   run<T_FMA, T_IDLE>("16 v_fma_f32", 16, 0);
   run<T_EXP, T_IDLE>("16 v_exp_f32", 16, 0);

@@ -226,7 +226,7 @@ def test_attention_fwd_bwd(lib, B, H, N, dh, dtype):
     assert relerr(out, o_tok) < tol, "forward output"
     assert (lse - lse_ref).abs().max().item() < (2e-2 if dtype == BF16 else 1e-4), "log-sum-exp"
     dqkv = torch.full((B * N, 3 * D), float("nan"), device="cuda", dtype=tdt)
-    delta = torch.empty(B, H, N, device="cuda")
+    delta = torch.empty(2, B, H, N, device="cuda")   # scratch: 2*B*H*N floats (include/siglip_hip.h)
     # the backward consumes the forward's own output (as the encoder does)
     ok(lib.sgl_op_attn_bwd(dtype, P(qkv[0]), P(qkv[1]), P(qkv[2]), P(out), P(dout_tok), P(lse), P(dqkv), P(delta), B, H,
                            N, dh, DP, stream()))
