@@ -15,6 +15,8 @@
 //
 // Roofline: MFMA-bound; algorithmic FLOPs fwd 4·N²·dh per (b,h), bwd 10·N²·dh (the two-kernel split executes
 // 14·N²·dh; the extra recompute buys determinism and no dQ atomics).
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -76,6 +78,43 @@ static inline dim3 head_grid(int nb, int BH) { return dim3((unsigned)(8 * ((BH +
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // ======================================================================================================
+// tile staging
+// ======================================================================================================
+// Staging (all three kernels): global -> LDS by DMA (buffer_load ... lds, 16 B per lane, 1 KiB per instruction); the two
+// backward kernels use three LDS stages, tile t+2 requested while tile t is computed.  One raw s_barrier per tile; no staging registers, no
+// ds_write, no address arithmetic in the loop beyond one add per DMA instruction.  The register-staged version it
+// replaces (load tile t+1 at the top, ds_write + barrier at the bottom) cost 24 % of the kernel: an ablation without the
+// staging ran 134 us faster of 560 (B = 64), half of it the ds_write -> lgkmcnt(0) -> barrier chain at the end of every tile.
+// An image row holds `SC` 16-byte chunks of which the first `NC` are data; DMA lanes of the pad chunks (and of rows past N)
+// point out of range and write zeros, so the pad columns the 80 -> 96 wide transposed reads touch are always clean.
+// The DMA goes through inline asm (see gemm_bf16_v2.hip): the kernel owns the vmcnt accounting for it.
+__device__ __forceinline__ void att_dma16(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
+               : "memory");
+}
+__device__ __forceinline__ void att_dma4(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
+               : "memory");
+}
+__device__ __forceinline__ u32x4 att_desc(const void* base, uint32_t bytes) {
+  const uint64_t q = (uint64_t)base;
+  return u32x4{(uint32_t)q, (uint32_t)(q >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+// global byte offset (tile 0) of image chunk `cidx` for a row-major source with `rowbytes` per row
+__device__ __forceinline__ uint32_t att_chunk_off(int cidx, int rows, int SC, int NC, uint32_t rowbytes) {
+  const int row = cidx / SC, col = cidx - row * SC;
+  return (row < rows && col < NC) ? (uint32_t)row * rowbytes + (uint32_t)col * 16u : SGL_OOB;
+}
+#define SGL_ATT_WAIT_BARRIER(n)                                   \
+  do {                                                            \
+    asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    __builtin_amdgcn_s_barrier();                                 \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    asm volatile("" ::: "memory");                                \
+  } while (0)
+
+// ======================================================================================================
 // forward
 // ======================================================================================================
 template <int DP>
@@ -86,9 +125,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   using C = AttnCfg<DP>;
   constexpr int KT = 64;
   constexpr int KBYTES = KT * C::RSTR, VBYTES = KT * C::TSTR, STAGE = KBYTES + VBYTES;
-  constexpr int NCH = KT * C::CPR, NQ = (NCH + 255) / 256;
+  constexpr int SCK = C::RSTR / 16, SCV = C::TSTR / 16;                       // 16-byte chunks per image row
+  constexpr int NIK = KT * SCK / 64, NIV = KT * SCV / 64, NSLOT = NIK + NIV;  // DMA instructions per image / per tile
+  constexpr int NPW = (NSLOT + 3) / 4;                                        // slots per wave
+  static_assert(KT * SCK % 64 == 0 && KT * SCV % 64 == 0, "whole DMA instructions per image");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   int bh, xb;
   if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
   const int b = bh / H, hd = bh - b * H;
@@ -96,10 +139,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
-
-  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+  const u32x4 dk_ = att_desc(K + mat, mbytes);
+  const u32x4 dv_ = att_desc(V + mat, mbytes);
+  const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
 
   const int qi = lane & 31, hh = lane >> 5;
   bf16x8 qf[C::KS];
@@ -107,26 +149,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int ks = 0; ks < C::KS; ++ks)
     qf[ks] = as_bf16x8(a_ldg(rq, (q0 + qi < N) ? (uint32_t)(((q0 + qi) * DP + 16 * ks + 8 * hh) * 2) : SGL_OOB));
 
-  u32x4 sk[NQ], sv[NQ];
-  auto load_tile = [&](int tile) {
+  // K/V tiles: global -> LDS by DMA (see the dK/dV kernel), two stages (three workgroups per CU leave no room for a third):
+  // tile+1 is requested right after the barrier that frees its stage and has the whole tile to land.  Slots sl = w + 4j;
+  // sl < NIK: K image (row reads), else V image (transposed reads); pad chunks of a row point out of range -> zeros.
+  uint32_t voff[NPW];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ch = t + q * 256;
-      const uint32_t off = (ch < NCH) ? (uint32_t)(tile * KT * DP * 2 + ch * 16) : SGL_OOB;
-      sk[q] = a_ldg(rk, off);
-      sv[q] = a_ldg(rv, off);
-    }
-  };
-  auto store_stage = [&](int stage) {
-    char* base = smem + stage * STAGE;
+  for (int j = 0; j < NPW; ++j) {
+    const int sl = w + 4 * j;
+    voff[j] = (sl < NIK) ? att_chunk_off(sl * 64 + lane, KT, SCK, DP / 8, (uint32_t)DP * 2u)
+                         : att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, DP / 8, (uint32_t)DP * 2u);
+  }
+  auto issue = [&](int stage) {
+    const uint32_t sb = lds0 + (uint32_t)(stage * STAGE);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int ch = t + q * 256;
-      if (ch < NCH) {
-        const int row = ch / C::CPR, cc = ch - row * C::CPR;
-        *reinterpret_cast<u32x4*>(base + row * C::RSTR + cc * 16) = sk[q];
-        *reinterpret_cast<u32x4*>(base + KBYTES + row * C::TSTR + cc * 16) = sv[q];
-      }
+    for (int j = 0; j < NPW; ++j) {
+      const int sl = w + 4 * j;
+      if (sl < NSLOT) att_dma16(sl < NIK ? dk_ : dv_, sb + (uint32_t)sl * 1024u, voff[j]);
+      voff[j] += (uint32_t)(KT * DP * 2);
     }
   };
 
@@ -138,13 +177,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
   const int ntiles = (N + KT - 1) / KT;
-  load_tile(0);
-  __syncthreads();  // zero fill done
-  store_stage(0);
-  __syncthreads();
+  // retire the Q fragment loads before the first DMA: the compiler's vmcnt bookkeeping does not see the DMA
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue(0);
   for (int tile = 0; tile < ntiles; ++tile) {
     const int cur = tile & 1;
-    if (tile + 1 < ntiles) load_tile(tile + 1);
+    SGL_ATT_WAIT_BARRIER(0);   // tile landed (own DMA; everyone's behind the barrier); the other stage is free
+    if (tile + 1 < ntiles) issue(cur ^ 1);
     const char* kb = smem + cur * STAGE;
     const char* vb = kb + KBYTES;
     f32x16 s0, s1;
@@ -199,8 +240,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) o[dt] = MFMA32(lds_trfrag(vb, C::TSTR, kk, dt * 32, lane), pb[kk], o[dt]);
-    if (tile + 1 < ntiles) store_stage(cur ^ 1);
-    __syncthreads();
   }
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l;
@@ -267,40 +306,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // ======================================================================================================
 // backward: dK, dV   (wave owns 32 keys; sweeps 32-query tiles staged in LDS)
 // ======================================================================================================
-// Staging (this kernel and the dQ kernel): global -> LDS by DMA (buffer_load ... lds, 16 B per lane, 1 KiB per instruction),
-// three LDS stages, tile t+2 requested while tile t is computed.  One raw s_barrier per tile; no staging registers, no
-// ds_write, no address arithmetic in the loop beyond one add per DMA instruction.  The register-staged version it
-// replaces (load tile t+1 at the top, ds_write + barrier at the bottom) cost 24 % of the kernel: an ablation without the
-// staging ran 134 us faster of 560 (B = 64), half of it the ds_write -> lgkmcnt(0) -> barrier chain at the end of every tile.
-// An image row holds `SC` 16-byte chunks of which the first `NC` are data; DMA lanes of the pad chunks (and of rows past N)
-// point out of range and write zeros, so the pad columns the 80 -> 96 wide transposed reads touch are always clean.
-// The DMA goes through inline asm (see gemm_bf16_v2.hip): the kernel owns the vmcnt accounting for it.
-__device__ __forceinline__ void att_dma16(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
-               : "memory");
-}
-__device__ __forceinline__ void att_dma4(u32x4 desc, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(desc)
-               : "memory");
-}
-__device__ __forceinline__ u32x4 att_desc(const void* base, uint32_t bytes) {
-  const uint64_t q = (uint64_t)base;
-  return u32x4{(uint32_t)q, (uint32_t)(q >> 32) & 0xffffu, bytes, 0x00020000u};
-}
-// global byte offset (tile 0) of image chunk `cidx` for a row-major source with `rowbytes` per row
-__device__ __forceinline__ uint32_t att_chunk_off(int cidx, int rows, int SC, int NC, uint32_t rowbytes) {
-  const int row = cidx / SC, col = cidx - row * SC;
-  return (row < rows && col < NC) ? (uint32_t)row * rowbytes + (uint32_t)col * 16u : SGL_OOB;
-}
-#define SGL_ATT_WAIT_BARRIER(n)                                   \
-  do {                                                            \
-    asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                            \
-    __builtin_amdgcn_s_barrier();                                 \
-    __builtin_amdgcn_sched_barrier(0);                            \
-    asm volatile("" ::: "memory");                                \
-  } while (0)
-
 template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                              const bf16* __restrict__ V, const bf16* __restrict__ dO,
@@ -514,11 +519,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
                                                             int B, int H, int N, int dh, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 32;
-  constexpr int KIMG = KT * C::DSTR, VIMG = KT * C::RSTR, STAGE = KIMG + VIMG;
-  constexpr int NCH = KT * C::CPR, NQ = (NCH + 255) / 256;
-  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int SCK = C::DSTR / 16, SCV = C::RSTR / 16;   // chunks per image row: K (dual-use image), V (row reads only)
+  constexpr int NIK = (KT * SCK + 63) / 64, NIV = (KT * SCV + 63) / 64;   // DMA instructions per image
+  constexpr int KIMG = NIK * 1024, VIMG = NIV * 1024, STAGE = KIMG + VIMG;
+  constexpr int NSLOT = NIK + NIV;
+  static_assert(NSLOT <= 16, "at most four DMA slots per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   int bh, xb;
   if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
   const int b = bh / H, hd = bh - b * H;
@@ -527,12 +535,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   const size_t mat = (size_t)bh * N * DP;
   const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
-
-  for (int i = t * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+  const u32x4 dk_ = att_desc(K + mat, mbytes);
+  const u32x4 dv_ = att_desc(V + mat, mbytes);
+  const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
 
   const int li = lane & 31, hh = lane >> 5;
   const int q = q0 + li;
@@ -546,27 +553,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   const float2 ax = (q < N) ? *reinterpret_cast<const float2*>(aux + 2 * ((size_t)bh * N + q)) : make_float2(-INFINITY, 0.f);
   const float Lq = ax.x, Dq = ax.y;   // -lse*log2e, -delta*scale (delta kernel)
 
-  u32x4 sk[NQ], sv[NQ];
-  auto load_tile = [&](int kt) {
+  // K/V tiles: global -> LDS by DMA, three stages, tile kt+2 requested while tile kt is computed (see the dK/dV kernel).
+  // This wave's slots: sl = w + 4j; sl < NIK: K image, else V image.
+  uint32_t voff[4];
+  u32x4 dsc[4];
+  uint32_t ldst[4];
 #pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) {
-      const int ch = t + qq * 256;
-      const uint32_t off = (ch < NCH) ? (uint32_t)(kt * KT * DP * 2 + ch * 16) : SGL_OOB;
-      sk[qq] = a_ldg(rk, off);
-      sv[qq] = a_ldg(rv, off);
+  for (int j = 0; j < 4; ++j) {
+    const int sl = w + 4 * j;
+    if (sl < NIK) {
+      voff[j] = att_chunk_off(sl * 64 + lane, KT, SCK, DP / 8, (uint32_t)DP * 2u);
+      dsc[j] = dk_;
+      ldst[j] = (uint32_t)sl * 1024u;
+    } else {
+      voff[j] = att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, DP / 8, (uint32_t)DP * 2u);
+      dsc[j] = dv_;
+      ldst[j] = (uint32_t)(KIMG + (sl - NIK) * 1024);
     }
-  };
-  auto store_stage = [&](int stage) {
-    char* base = smem + stage * STAGE;
-#pragma unroll
-    for (int qq = 0; qq < NQ; ++qq) {
-      const int ch = t + qq * 256;
-      if (ch < NCH) {
-        const int row = ch / C::CPR, cc = ch - row * C::CPR;
-        *reinterpret_cast<u32x4*>(base + row * C::DSTR + cc * 16) = sk[qq];
-        *reinterpret_cast<u32x4*>(base + KIMG + row * C::RSTR + cc * 16) = sv[qq];
-      }
-    }
+  }
+  auto issue1 = [&](int j, int stage) {   // tiles past the end read out of range: zeros into a stage nobody reads again
+    if (w + 4 * j < NSLOT) att_dma16(dsc[j], lds0 + (uint32_t)(stage * STAGE) + ldst[j], voff[j]);
+    voff[j] += (uint32_t)(KT * DP * 2);
   };
 
   f32x16 dq[C::DT];
@@ -576,15 +583,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
   const int ntiles = (N + KT - 1) / KT;
-  load_tile(0);
-  __syncthreads();
-  store_stage(0);
-  __syncthreads();
+  // retire the register loads before the first DMA: the compiler's vmcnt bookkeeping does not see the DMA
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(qf[ks]), "v"(dof[ks]));
+  asm volatile("" ::"v"(Lq), "v"(Dq));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(j, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue1(j, 1);
+  int st = 0;
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < ntiles) load_tile(kt + 1);
-    const char* kimg = smem + cur * STAGE;
+    // tile kt has landed (own DMA: all but the younger tile's; everyone's: barrier); the stage of tile kt-1 is free
+    const int nw = (NSLOT - w + 3) / 4;           // this wave's DMA instructions per tile
+    if (nw >= 4) SGL_ATT_WAIT_BARRIER(4);
+    else if (nw == 3) SGL_ATT_WAIT_BARRIER(3);
+    else if (nw == 2) SGL_ATT_WAIT_BARRIER(2);
+    else SGL_ATT_WAIT_BARRIER(1);
+    const int st_next = (st == 0) ? 2 : st - 1;
+    const char* kimg = smem + st * STAGE;
     const char* vimg = kimg + KIMG;
+    st = (st == 2) ? 0 : st + 1;
     f32x16 S, dP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
@@ -634,13 +653,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     bf16x8 dsb[2];
     dsb[0] = pack8(dP, 0);
     dsb[1] = pack8(dP, 8);
+    // dQᵀ += Kᵀ·dSᵀ, with the request for tile kt+2 spread behind the MFMAs (see the dK/dV kernel)
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+    for (int i = 0; i < 2 * C::DT; ++i) {
+      dq[i >> 1] = MFMA32(kt_frag[i >> 1][i & 1], dsb[i & 1], dq[i >> 1]);
+      if (i < 4) issue1(i, st_next);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) dq[dt] = MFMA32(kt_frag[dt][kk], dsb[kk], dq[dt]);
-    if (kt + 1 < ntiles) store_stage(cur ^ 1);
-    __syncthreads();
+    for (int j = 2 * C::DT; j < 4; ++j) issue1(j, st_next);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing out-of-range requests
   if (q < N) {
     bf16* qrow = dqkv + ((size_t)b * N + q) * (3 * (size_t)D) + hd * dh;
 #pragma unroll
@@ -684,7 +707,7 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   constexpr int smem_kv = 3 * (2 * ((32 * (C::DSTR / 16) + 63) / 64) * 1024 + 32 * 8);
-  constexpr int smem_q = 2 * (32 * C::DSTR + 32 * C::RSTR);
+  constexpr int smem_q = 3 * (((32 * (C::DSTR / 16) + 63) / 64) + ((32 * (C::RSTR / 16) + 63) / 64)) * 1024;
   const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
   hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
   e = hipGetLastError();
