@@ -108,48 +108,61 @@ hipError_t layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 // residual-branch gradient; optional low-precision copy of dx feeds the next backward GEMM's A operand.
 // dgamma/dbeta/colsum(dx): per-lane register partials over the block's rows -> LDS -> partial[block][3D].
 template <typename TDy, typename TLp, int LN_MAXV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, int lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (LN_MAXV <= 5 ? 3 : 1)) void ln_bwd_kernel(const TDy* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, TLp* __restrict__ dx_lp,
                                                      float* __restrict__ partial, int M, int D) {
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][D]
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4][D] fold buffer, then gamma[D]
   const int lane = lane_id(), w = wave_id();
   const int nv = D >> 2;
-  f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], ds[LN_MAXV];  // ds: column sums of the dx written
+  // gamma lives in LDS, not in 20 registers, and a row's x / dy stay RAW in registers between the two passes (dy packed as
+  // loaded): that frees the registers to request the row's residual-gradient chunk together with x and dy, so a row
+  // exposes ONE memory round trip instead of two (the second pass used to start with the dres load) at the same 3 waves/SIMD.
+  float* gsm = ln_smem + (size_t)4 * D;
+  for (int j = threadIdx.x; j < D; j += 256) gsm[j] = gamma[j];
+  __syncthreads();
+  using DyVec = __attribute__((ext_vector_type(4))) TDy;
+  f32x4 dg[LN_MAXV], db[LN_MAXV], ds[LN_MAXV];  // ds: column sums of the dx written
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = lane + i * 64;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     dg[i] = z;
     db[i] = z;
     ds[i] = z;
-    gam[i] = (c < nv) ? reinterpret_cast<const f32x4*>(gamma)[c] : z;
   }
   const float invD = 1.0f / (float)D;
   for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
     const TDy* dyr = dy + (size_t)row * lddy;
+    const f32x4* rr = dres ? reinterpret_cast<const f32x4*>(dres + (size_t)row * D) : nullptr;
+    f32x4 xv[LN_MAXV], rv[LN_MAXV];
+    DyVec dv[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        xv[i] = xr[c];
+        dv[i] = *reinterpret_cast<const DyVec*>(dyr + c * 4);
+        if (rr) rv[i] = rr[c];
+      }
+    }
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[LN_MAXV], gy[LN_MAXV];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
-        const f32x4 xv = xr[c];
-        float d[4];
-        Vec<TDy, 4>::ld(dyr + c * 4, d);
+        const f32x4 gm = reinterpret_cast<const f32x4*>(gsm)[c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float h = (xv[j] - mu) * rs;
-          const float g = d[j] * gam[i][j];
-          xh[i][j] = h;
-          gy[i][j] = g;
+          const float d = (float)dv[i][j];
+          const float h = (xv[i][j] - mu) * rs;
+          const float g = d * gm[j];
           c1 += g;
           c2 += g * h;
-          dg[i][j] += d[j] * h;
-          db[i][j] += d[j];
+          dg[i][j] += d * h;
+          db[i][j] += d;
         }
       }
     }
@@ -160,13 +173,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
+        const f32x4 gm = reinterpret_cast<const f32x4*>(gsm)[c];
         float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rs * (gy[i][j] - c1 - xh[i][j] * c2);
-        if (dres) {
-          const f32x4 r = reinterpret_cast<const f32x4*>(dres + (size_t)row * D)[c];
+        for (int j = 0; j < 4; ++j) {
+          const float h = (xv[i][j] - mu) * rs;           // same operations as the first pass: bit-identical h, g
+          const float g = (float)dv[i][j] * gm[j];
+          o[j] = rs * (g - c1 - h * c2);
+        }
+        if (rr) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += r[j];
+          for (int j = 0; j < 4; ++j) o[j] += rv[i][j];
         }
         Vec<float, 4>::st(dxr + c * 4, o);
 #pragma unroll
@@ -204,7 +221,7 @@ static hipError_t ln_bwd_launch2(const void* dy, int lddy, const float* x, const
                                  const float* gamma, const float* dres, float* dx, void* dx_lp, float* partial,
                                  int nblk, int M, int D, hipStream_t s) {
   dim3 grid(nblk), block(256);
-  const size_t smem = (size_t)4 * D * sizeof(float);
+  const size_t smem = (size_t)5 * D * sizeof(float);   // [4][D] fold buffer + gamma[D]
 #define SGL_LNB(V)                                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<TDy, TLp, V>), grid, block, smem, s, (const TDy*)dy, lddy, x, mean, rstd, gamma, \
                      dres, dx, (TLp*)dx_lp, partial, M, D)
