@@ -9,7 +9,8 @@
 // the row max / row sum are lane-local plus one cross-half shuffle, the running rescale factor is a per-lane
 // scalar, and Oᵀ = Vᵀ·Pᵀ consumes the Sᵀ accumulator registers directly as the MFMA B operand (no LDS round
 // trip for P).  Vᵀ fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16.
-// Backward recomputes P from the saved log-sum-exp.  Two kernels (after the delta pre-pass), no atomics, bitwise reproducible:
+// Backward recomputes P from the saved log-sum-exp.  Two kernels, no atomics, bitwise reproducible (the dQ kernel runs first
+// and also produces delta = rowsum(dO ∘ O) for the dK/dV kernel):
 //   kv-kernel ("key on the lane"):  S = Q·Kᵀ, dP = dO·Vᵀ, dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS   (wave owns 32 keys)
 //   q-kernel  ("query on the lane"): Sᵀ = K·Qᵀ, dPᵀ = V·dOᵀ, dQᵀ += Kᵀ·dSᵀ             (wave owns 32 queries)
 //
@@ -263,47 +264,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ======================================================================================================
-// backward: delta = rowsum(dO ∘ O)
-// ======================================================================================================
-// One wave per token row: 16-byte coalesced loads of the whole [H*dh] row, per-chunk partial sums, then a
-// segmented sum of the dh/8 chunks of each head.  HBM-bound: 2 * D * 2 bytes per token.
-// Output aux[b][h][n] = {-lse * log2(e), -delta * scale}: the addends of the two backward kernels' fused multiply-adds
-// (p = exp2(S*c + aux.x), dS = p * (dP*scale + aux.y)).
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO,
-                                                         const float* __restrict__ lse, float* __restrict__ aux, int B, int H,
-                                                         int N, int dh, float scale) {
-  __shared__ float part[4][256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t tok = (size_t)blockIdx.x * 4 + w;
-  const size_t ntok = (size_t)B * N;
-  const int D = H * dh, nch = D >> 3, cph = dh >> 3;  // chunks per row, chunks per head
-  if (tok < ntok) {
-    const bf16* o = O + tok * D;
-    const bf16* d = dO + tok * D;
-    for (int c = lane; c < nch; c += 64) {
-      float a[8], g[8];
-      Vec<bf16, 8>::ld(o + c * 8, a);
-      Vec<bf16, 8>::ld(d + c * 8, g);
-      float acc = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) acc = fmaf(a[r], g[r], acc);
-      part[w][c] = acc;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (tok < ntok) {
-    const int b = (int)(tok / N), i = (int)(tok - (size_t)b * N);
-    for (int h = lane; h < H; h += 64) {
-      float acc = 0.f;
-      for (int c = 0; c < cph; ++c) acc += part[w][h * cph + c];
-      // the two per-query constants of the backward, pre-scaled for the kernels' exp2 / dS forms, as one 8-byte pair
-      const size_t idx = ((size_t)b * H + h) * N + i;
-      *reinterpret_cast<float2*>(aux + 2 * idx) = make_float2(-lse[idx] * 1.4426950408889634f, -acc * scale);
-    }
-  }
-}
-
-// ======================================================================================================
 // backward: dK, dV   (wave owns 32 keys; sweeps 32-query tiles staged in LDS)
 // ======================================================================================================
 template <int DP>
@@ -447,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
     for (int i = 0; i < PRE; ++i) fr[i] = frag(i);
     __builtin_amdgcn_sched_barrier(0);
     // S[r], dP[r]: query row (r&3) + 8*(r>>2) + 4*hh of the tile, key = lane & 31;  ld[2*row] = -lse*log2e, ld[2*row+1] =
-    // -delta*scale (delta kernel): p = exp2(S*c - lse*log2e), dS = p * (dP*scale - delta*scale)
+    // -delta*scale (written by the dQ kernel): p = exp2(S*c - lse*log2e), dS = p * (dP*scale - delta*scale)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 A0 = *reinterpret_cast<const f32x4*>(ld + 2 * (8 * g4 + 4 * hh));
@@ -514,8 +474,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
 // ======================================================================================================
 template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                            const bf16* __restrict__ V, const bf16* __restrict__ dO,
-                                                            const float* __restrict__ aux, bf16* __restrict__ dqkv,
+                                                            const bf16* __restrict__ V, const bf16* __restrict__ O,
+                                                            const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                            float* __restrict__ aux, bf16* __restrict__ dqkv,
                                                             int B, int H, int N, int dh, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 32;
@@ -524,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   constexpr int KIMG = NIK * 1024, VIMG = NIV * 1024, STAGE = KIMG + VIMG;
   constexpr int NSLOT = NIK + NIV;
   static_assert(NSLOT <= 16, "at most four DMA slots per wave");
+  constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -550,8 +512,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
     qf[ks] = as_bf16x8(a_ldg(rq, (q < N) ? (uint32_t)((q * DP + col) * 2) : SGL_OOB));
     dof[ks] = as_bf16x8(a_ldg(rdo, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
   }
-  const float2 ax = (q < N) ? *reinterpret_cast<const float2*>(aux + 2 * ((size_t)bh * N + q)) : make_float2(-INFINITY, 0.f);
-  const float Lq = ax.x, Dq = ax.y;   // -lse*log2e, -delta*scale (delta kernel)
+  // delta = rowsum(dO ∘ O) of this lane's query, computed here (each lane holds half of its row of dO; O's half is loaded
+  // once) instead of in a pre-pass over O and dO; the pair {-lse*log2e, -delta*scale} is what both backward kernels add
+  // inside their fused multiply-adds, and the dK/dV kernel (launched after this one) streams it from `aux`.
+  float dl = 0.f;
+  {
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(O + (size_t)b * N * D + hd * dh, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int col = 16 * ks + 8 * hh;
+      const bf16x8 of = as_bf16x8(a_ldg(ro, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl = fmaf((float)of[j], (float)dof[ks][j], dl);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+  }
+  const float Lq = (q < N) ? -lse[(size_t)bh * N + q] * LOG2E : -INFINITY;
+  const float Dq = (q < N) ? -dl * scale : 0.f;
+  if (q < N && hh == 0) *reinterpret_cast<float2*>(aux + 2 * ((size_t)bh * N + q)) = make_float2(Lq, Dq);
 
   // K/V tiles: global -> LDS by DMA, three stages, tile kt+2 requested while tile kt is computed (see the dK/dV kernel).
   // This wave's slots: sl = w + 4j; sl < NIK: K image, else V image.
@@ -701,18 +679,14 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   using C = AttnCfg<DP>;
   const float scale = 1.0f / sqrtf((float)dh);
   const float c = scale * 1.4426950408889634f;
-  const size_t ntok = (size_t)B * N;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, out, dout, lse, delta, B, H, N,
-                     dh, scale);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  // dQ first: it also computes delta and leaves the {-lse*log2e, -delta*scale} pairs in `delta` for the dK/dV kernel
   constexpr int smem_kv = 3 * (2 * ((32 * (C::DSTR / 16) + 63) / 64) * 1024 + 32 * 8);
   constexpr int smem_q = 3 * (((32 * (C::DSTR / 16) + 63) / 64) + ((32 * (C::RSTR / 16) + 63) / 64)) * 1024;
   const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
-  e = hipGetLastError();
+  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N, dh, c, scale);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
   return hipGetLastError();
 }
 
@@ -721,7 +695,6 @@ static bool attn_shape_ok(int N, int dh, int DP, int H) {
   if (DP != 16 && DP != 32 && DP != 48 && DP != 64 && DP != 80 && DP != 96) return false;
   if ((size_t)N * DP * 2 >= (1ull << 31)) return false;
   if ((size_t)N * H * dh * 2 >= (1ull << 31)) return false;
-  if (H * dh > 2048) return false;  // delta kernel: 256 chunks of 8 per row
   return true;
 }
 
