@@ -322,67 +322,103 @@ hipError_t cast_f32(const float* src, void* dst, int dst_dtype, size_t n, hipStr
 }
 
 // ---- attention-pool head: one probe query per image (TF:modeling_siglip.py:633-637, nn.MultiheadAttention
-//      with q = probe, k = v = tokens).  One block per (b, h).  < 0.1 % of the FLOPs. ---------------------
+//      with q = probe, k = v = tokens).  One block per (b, h).  < 0.1 % of the FLOPs, HBM-bound: K and V of the
+//      head are read once, in 16-byte (bf16) / 32-byte (fp32) chunks with consecutive lanes on consecutive chunks.
+//      Thread t of the first RP*CPR (RP = 256 / CPR rows per pass, CPR = DP/8 chunks per row) owns chunk column
+//      t % CPR for rows t / CPR, + RP, + 2 RP, ...: its slice of q / dO stays in registers. ---------------------
+template <typename T>
+__device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pool_attn_fwd_kernel(const float* __restrict__ q, const T* __restrict__ K,
                                                             const T* __restrict__ V, T* __restrict__ out,
                                                             float* __restrict__ probs, int H, int N, int dh, int DP) {
-  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N] scores + [256] scratch + [dh] q
-  float* sc = pa_smem;
-  float* red = pa_smem + N;
-  float* qs = red + 256;
+  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N*CPR] chunk partials, [N] probabilities, [8] scratch
+  const int CPR = DP >> 3, RP = 256 / CPR;
+  float* part = pa_smem;
+  float* pr = part + (size_t)N * CPR;
+  float* red = pr + N;
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const T* Kb = K + (size_t)bh * N * DP;
   const T* Vb = V + (size_t)bh * N * DP;
   const float scale = rsqrtf((float)dh);
-  for (int d = threadIdx.x; d < dh; d += 256) qs[d] = q[h * dh + d];
+  const int t = threadIdx.x, c = t % CPR, r0 = t / CPR;
+  const bool act = t < RP * CPR;
+  float qv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qv[j] = (c * 8 + j < dh) ? q[h * dh + c * 8 + j] : 0.f;
+  if (act)
+    for (int n = r0; n < N; n += RP) {
+      float kv[8];
+      Vec<T, 8>::ld(Kb + (size_t)n * DP + c * 8, kv);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(qv[j], kv[j], s);
+      part[n * CPR + c] = s;
+    }
   __syncthreads();
   float mx = -INFINITY;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  for (int n = t; n < N; n += 256) {
     float s = 0.f;
-    for (int d = 0; d < dh; ++d) s += qs[d] * Elem<T>::ld(Kb + (size_t)n * DP + d);
+    for (int j = 0; j < CPR; ++j) s += part[n * CPR + j];
     s *= scale;
-    sc[n] = s;
+    pr[n] = s;
     mx = fmaxf(mx, s);
   }
-  red[threadIdx.x] = mx;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-    __syncthreads();
-  }
-  mx = red[0];
-  __syncthreads();
+  mx = block_reduce_256<T>(mx, red, true);
   float sum = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float e = __expf(sc[n] - mx);
-    sc[n] = e;
+  for (int n = t; n < N; n += 256) {
+    const float e = __expf(pr[n] - mx);
+    pr[n] = e;
     sum += e;
   }
-  red[threadIdx.x] = sum;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  const float inv = 1.0f / red[0];
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float p = sc[n] * inv;
-    sc[n] = p;
-    probs[(size_t)bh * N + n] = p;
+  sum = block_reduce_256<T>(sum, red, false);
+  const float inv = 1.0f / sum;
+  for (int n = t; n < N; n += 256) {
+    const float pv = pr[n] * inv;
+    pr[n] = pv;
+    probs[(size_t)bh * N + n] = pv;
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < dh; d += 256) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += sc[n] * Elem<T>::ld(Vb + (size_t)n * DP + d);
-    Elem<T>::st(out + (size_t)b * H * dh + h * dh + d, acc);
+  // out[d] = sum_n p_n V[n, d]: per-thread partial over its rows, then the RP threads of a chunk column through LDS
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (act)
+    for (int n = r0; n < N; n += RP) {
+      float vv[8];
+      Vec<T, 8>::ld(Vb + (size_t)n * DP + c * 8, vv);
+      const float pv = pr[n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(pv, vv[j], acc[j]);
+    }
+  __syncthreads();   // part[] is free again
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[(r0 * CPR + c) * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int d = t; d < dh; d += 256) {
+    float a = 0.f;
+    for (int r = 0; r < RP; ++r) a += part[(r * CPR + (d >> 3)) * 8 + (d & 7)];
+    Elem<T>::st(out + (size_t)b * H * dh + h * dh + d, a);
   }
 }
 
 hipError_t pool_attn_fwd(const float* q, const void* K, const void* V, int dtype, void* out, float* probs, int B,
                          int H, int N, int dh, int DP, hipStream_t s) {
   if (B * H == 0) return hipSuccess;
-  const size_t smem = (size_t)(N + 256 + dh) * sizeof(float);
+  if (DP % 8 || DP < 8 || DP > 2048) return hipErrorInvalidValue;
+  const int CPR = DP / 8;
+  const size_t need = (size_t)N * CPR > (size_t)256 * 8 ? (size_t)N * CPR : (size_t)256 * 8;
+  const size_t smem = (need + N + 8) * sizeof(float);
+  if (smem > 64 * 1024) return hipErrorInvalidValue;   // N * DP / 8 chunk partials must fit the default LDS window
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(pool_attn_fwd_kernel<bf16>, dim3(B * H), dim3(256), smem, s, q, (const bf16*)K, (const bf16*)V,
                        (bf16*)out, probs, H, N, dh, DP);
@@ -401,51 +437,81 @@ __global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dout, T* __restrict__ dkv,
                                                             float* __restrict__ dq_partial, int H, int N, int dh,
                                                             int DP) {
-  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N] ds + [256] red + [dh] q + [dh] do
-  float* ds = pa_smem;
-  float* red = pa_smem + N;
-  float* qs = red + 256;
-  float* dos = qs + dh;
+  extern __shared__ __attribute__((aligned(16))) float pa_smem[];  // [N*CPR] chunk partials, [N] ds, [N] p, [8] scratch
+  const int CPR = DP >> 3, RP = 256 / CPR;
+  float* part = pa_smem;
+  float* ds = part + (size_t)N * CPR;
+  float* pr = ds + N;
+  float* red = pr + N;
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const int D = H * dh;
   const T* Kb = K + (size_t)bh * N * DP;
   const T* Vb = V + (size_t)bh * N * DP;
   const float scale = rsqrtf((float)dh);
-  for (int d = threadIdx.x; d < dh; d += 256) {
-    qs[d] = q[h * dh + d];
-    dos[d] = dout[(size_t)b * D + h * dh + d];
+  const int t = threadIdx.x, c = t % CPR, r0 = t / CPR;
+  const bool act = t < RP * CPR;
+  const bool real = c * 8 < dh;     // dh % 8 == 0: a chunk is entirely data or entirely pad
+  float qv[8], dov[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    qv[j] = real ? q[h * dh + c * 8 + j] : 0.f;
+    dov[j] = real ? dout[(size_t)b * D + h * dh + c * 8 + j] : 0.f;
   }
-  __syncthreads();
-  float part = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float dp = 0.f;
-    for (int d = 0; d < dh; ++d) dp += dos[d] * Elem<T>::ld(Vb + (size_t)n * DP + d);
-    ds[n] = dp;
-    part += probs[(size_t)bh * N + n] * dp;
-  }
-  red[threadIdx.x] = part;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  const float dot = red[0];
-  __syncthreads();
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float p = probs[(size_t)bh * N + n];
-    const float g = p * (ds[n] - dot) * scale;
-    ds[n] = g;
-    T* row = dkv + ((size_t)b * N + n) * (2 * D);
-    for (int d = 0; d < dh; ++d) {
-      Elem<T>::st(row + h * dh + d, g * qs[d]);
-      Elem<T>::st(row + D + h * dh + d, p * dos[d]);
+  if (act)
+    for (int n = r0; n < N; n += RP) {
+      float vv[8];
+      Vec<T, 8>::ld(Vb + (size_t)n * DP + c * 8, vv);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(dov[j], vv[j], s);
+      part[n * CPR + c] = s;
     }
+  __syncthreads();
+  float psum = 0.f;
+  for (int n = t; n < N; n += 256) {
+    float dp = 0.f;
+    for (int j = 0; j < CPR; ++j) dp += part[n * CPR + j];
+    const float pv = probs[(size_t)bh * N + n];
+    ds[n] = dp;
+    pr[n] = pv;
+    psum += pv * dp;
+  }
+  const float dot = block_reduce_256<T>(psum, red, false);
+  for (int n = t; n < N; n += 256) ds[n] = pr[n] * (ds[n] - dot) * scale;
+  __syncthreads();
+  // dK / dV rows (16-byte chunks, 9 consecutive lanes per 144-byte row segment) and the per-thread part of dq
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (act)
+    for (int n = r0; n < N; n += RP) {
+      float kv[8];
+      Vec<T, 8>::ld(Kb + (size_t)n * DP + c * 8, kv);
+      const float g = ds[n], pv = pr[n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, kv[j], acc[j]);
+      if (real) {
+        float ok[8], ov[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ok[j] = g * qv[j];
+          ov[j] = pv * dov[j];
+        }
+        T* row = dkv + ((size_t)b * N + n) * (2 * (size_t)D) + h * dh + c * 8;
+        Vec<T, 8>::st(row, ok);
+        Vec<T, 8>::st(row + D, ov);
+      }
+    }
+  __syncthreads();   // part[] is free again
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[(r0 * CPR + c) * 8 + j] = acc[j];
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < dh; d += 256) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += ds[n] * Elem<T>::ld(Kb + (size_t)n * DP + d);
-    dq_partial[(size_t)b * D + h * dh + d] = acc;
+  for (int d = t; d < dh; d += 256) {
+    float a = 0.f;
+    for (int r = 0; r < RP; ++r) a += part[(r * CPR + (d >> 3)) * 8 + (d & 7)];
+    dq_partial[(size_t)b * D + h * dh + d] = a;
   }
 }
 
@@ -453,7 +519,11 @@ hipError_t pool_attn_bwd(const float* q, const void* K, const void* V, int dtype
                          const float* dout, void* dkv, float* dq_partial, int B, int H, int N, int dh, int DP,
                          hipStream_t s) {
   if (B * H == 0) return hipSuccess;
-  const size_t smem = (size_t)(N + 256 + 2 * dh) * sizeof(float);
+  if (DP % 8 || dh % 8 || DP < 8 || DP > 2048) return hipErrorInvalidValue;
+  const int CPR = DP / 8;
+  const size_t need = (size_t)N * CPR > (size_t)256 * 8 ? (size_t)N * CPR : (size_t)256 * 8;
+  const size_t smem = (need + 2 * (size_t)N + 8) * sizeof(float);
+  if (smem > 64 * 1024) return hipErrorInvalidValue;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(pool_attn_bwd_kernel<bf16>, dim3(B * H), dim3(256), smem, s, q, (const bf16*)K, (const bf16*)V,
                        probs, dout, (bf16*)dkv, dq_partial, H, N, dh, DP);
