@@ -170,6 +170,29 @@ hipError_t batch_sum(const float* in, int B, size_t n, float* out, int accumulat
   return hipGetLastError();
 }
 
+// out[j] (+)= sum_i v[i] * W[i*cols + j]: a row vector times a row-major fp32 matrix (64 columns per block, 4 row groups
+// folded through LDS in fixed order).  Used for the v_proj bias gradient, see encoder.hip.
+__global__ __launch_bounds__(256) void vecmat_f32_kernel(const float* __restrict__ v, const float* __restrict__ W, int rows,
+                                                         int cols, float* __restrict__ out, int accumulate) {
+  __shared__ float part[4][64];
+  const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jj;
+  float s = 0.f;
+  if (j < cols)
+    for (int i = rg; i < rows; i += 4) s = fmaf(v[i], W[(size_t)i * cols + j], s);
+  part[rg][jj] = s;
+  __syncthreads();
+  if (rg == 0 && j < cols) {
+    const float r = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
+    out[j] = accumulate ? out[j] + r : r;
+  }
+}
+hipError_t vecmat_f32(const float* v, const float* W, int rows, int cols, float* out, int accumulate, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(vecmat_f32_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, s, v, W, rows, cols, out, accumulate);
+  return hipGetLastError();
+}
+
 // ---- position-table bicubic resize (F.interpolate bicubic, align_corners=False, A=-0.75;
 //      TF:modeling_siglip.py:137-173).  Runs once per resolution; tiny. ---------------------------------
 __device__ __forceinline__ void cubic_coeffs(float t, float* w) {

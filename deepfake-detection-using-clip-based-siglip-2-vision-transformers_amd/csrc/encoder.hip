@@ -825,8 +825,10 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
   else
     RET(bias_grad(ctx, lay, ws, du, Ip, M, Ip, I, lg.fc1_b, acc, s));
   // LN2 backward: dx := dx + LN2'(dh2);  gbuf := lowp(dx);  colsum(dx) is the out_proj bias gradient
+  // (the column sums stay in gsum as well: the v_proj bias gradient below is a function of them)
   RET(ln_backward(ctx, lay, ws, dhb, dt, xmid, reinterpret_cast<const float*>(lb + lay.r_stats2), M, lw.ln2_w, dx, dx,
-                  gbuf, lg.ln2_w, lg.ln2_b, acc, s, lg.o_b, acc));
+                  gbuf, lg.ln2_w, lg.ln2_b, acc, s, (lg.o_b || lg.v_b) ? gsum : nullptr, 0));
+  if (lg.o_b) CK(batch_sum(gsum, 1, (size_t)D, lg.o_b, acc, s));
 
   // ---- attention: xmid = x_in + out_proj(attn(qkv(LN1 x_in)))
   {
@@ -847,14 +849,21 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
     float* gb[3] = {lg.q_b, lg.k_b, lg.v_b};
     // when the caller laid the three gradients out back to back (the Python host does), q/k/v are one GEMM
     const bool w_adj = gw[0] && gw[1] == gw[0] + (size_t)D * D && gw[2] == gw[1] + (size_t)D * D;
-    const bool b_adj = gb[0] && gb[1] == gb[0] + D && gb[2] == gb[1] + D;
     if (w_adj) CK(gemm_tn(ctx, dqkv, 3 * D, lb + lay.r_h1, D, M, 3 * D, D, gw[0], D, acc, s, sws, kSplitWsBytes));
-    if (b_adj) RET(bias_grad(ctx, lay, ws, dqkv, 3 * D, M, 3 * D, 3 * D, gb[0], acc, s));
     for (int j = 0; j < 3; ++j) {
       const char* aj = reinterpret_cast<const char*>(dqkv) + (size_t)j * D * ctx->es;
       if (!w_adj && gw[j]) CK(gemm_tn(ctx, aj, 3 * D, lb + lay.r_h1, D, M, D, D, gw[j], D, acc, s, sws, kSplitWsBytes));
-      if (!b_adj) RET(bias_grad(ctx, lay, ws, aj, 3 * D, M, D, D, gb[j], acc, s));
     }
+    // Bias gradients of the three projections = column sums of dQ, dK, dV over all tokens.  Only dQ's needs a pass:
+    //   sum_n dK[n,:] = sum_q Q[q,:] * scale * (sum_n dS[q,n]) and sum_n dS[q,n] = sum_n P (dP - delta) = delta - delta = 0:
+    //     the k_proj bias has NO gradient (softmax is invariant to a per-query shift of the scores) — exact zeros here,
+    //     rounding noise around zero in the reference;
+    //   sum_n dV[n,:] = sum_q dO[q,:] * (sum_n P[q,n]) = sum_q dO[q,:] = colsum(dY) * W_o, and colsum(dY) is the out_proj bias
+    //     gradient the LayerNorm backward above already produced (gsum): a 1152-vector times W_o instead of a read of dV.
+    // (One column-sum pass over a third of dqkv instead of all of it: 116 -> ~40 us per block at B = 128.)
+    if (gb[0]) RET(bias_grad(ctx, lay, ws, dqkv, 3 * D, M, D, D, gb[0], acc, s));
+    if (gb[1] && !acc) CK(hipMemsetAsync(gb[1], 0, (size_t)D * 4, s));
+    if (gb[2]) CK(vecmat_f32(gsum, lw.o_w, D, D, gb[2], acc, s));
   }
   if (d_tap) CK(add_f32(dx, d_tap, dx, (size_t)M * D, s));
   const bool ln1_params = lg.ln1_w || lg.ln1_b;
