@@ -49,8 +49,12 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
     const int hc = col - which * dm;
     const int h = hc / p.head_dim;
     const int d = hc - h * p.head_dim;
-    const int b = row / p.tokens;
-    const int n = row - b * p.tokens;
+    // row / tokens without the ~35-instruction integer division (16 of them per thread and tile otherwise): float
+    // reciprocal estimate, then one exact correction step (rows < 2^22)
+    int b = (int)((float)row * __builtin_amdgcn_rcpf((float)p.tokens));
+    int n = row - b * p.tokens;
+    if (n < 0) { b -= 1; n += p.tokens; }
+    else if (n >= p.tokens) { b += 1; n -= p.tokens; }
     float bb[NV];
     Vec<float, NV>::ld(p.bias + col, bb);
 #pragma unroll
