@@ -321,6 +321,9 @@ hipError_t gemm_tn2_bf16(const void* A, int lda, const void* B, int ldb, int Mre
 // persistent generation 7 (gemm_bf16_v3.hip); hipErrorNotSupported = outside its envelope, fall back to generation 6
 hipError_t gemm_nt7_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, int out_dtype,
                          const EpiParams& p, hipStream_t s);
+// four-wave generation 8 (gemm_bf16_v4.hip), opt-in with SGL_GEMM_GEN=8; hipErrorNotSupported = fall back to generation 6
+hipError_t gemm_nt8_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, int out_dtype,
+                         const EpiParams& p, hipStream_t s);
 // SGL_GEMM_GEN=1 forces the 128x128 register-staged kernels (A/B comparisons)
 static int gemm_generation() {
   static int gen = -1;
@@ -359,6 +362,11 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
     static const bool gen7 = getenv("SGL_GEMM_GEN") && atoi(getenv("SGL_GEMM_GEN")) == 7;
     if (gen7) {
       const hipError_t e = gemm_nt7_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
+      if (e != hipErrorNotSupported) return e;
+    }
+    static const bool gen8 = getenv("SGL_GEMM_GEN") && atoi(getenv("SGL_GEMM_GEN")) == 8;
+    if (gen8) {
+      const hipError_t e = gemm_nt8_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
       if (e != hipErrorNotSupported) return e;
     }
     return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
