@@ -64,4 +64,4 @@ for name, N, K, epi, Na, Ka in shapes:
     fl = 2.0 * M * Na * Ka
     tot_t += t; tot_f += fl
     print(f"{name:16s} M={M} N={N} K={K}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s{err}", flush=True)
-print(f"sum: {tot_t*1e3:.3f} ms  {tot_f/tot_t/1e12:.1f} TF/s  (gen {os.environ.get('SGL_GEMM_GEN', '7')})")
+print(f"sum: {tot_t*1e3:.3f} ms  {tot_f/tot_t/1e12:.1f} TF/s  (gen {os.environ.get('SGL_GEMM_GEN', '6')})")

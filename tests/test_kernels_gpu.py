@@ -350,3 +350,17 @@ def test_gemm_tn_with_scratch_is_reproducible_and_correct(lib):
     ok(lib.sgl_op_gemm_tn_ws(BF16, P(A), N1, P(B), N2, Mred, N1, N2, 0, P(acc), N2, 1, P(scratch), scratch.numel(),
                              torch.cuda.current_stream().cuda_stream))
     assert relerr(acc, 2 * outs[0]) < 1e-6
+
+
+@pytest.mark.parametrize("gen", ["7", "8"])
+def test_opt_in_nt_gemm_generations_are_correct(gen):
+    """The opt-in NT GEMM generations (SGL_GEMM_GEN=7 persistent, =8 four-wave; DESIGN.md negative results) stay correct on
+    the encoder's eight shapes: tests/bench_nt.py checks every launch against torch (head, tail rows, pad columns) and
+    asserts.  The generation is latched per process, hence the subprocess."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGL_GEMM_GEN=gen)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "bench_nt.py"), "8"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("relerr") == 8, r.stdout
