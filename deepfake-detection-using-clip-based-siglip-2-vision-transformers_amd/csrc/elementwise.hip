@@ -170,27 +170,32 @@ hipError_t batch_sum(const float* in, int B, size_t n, float* out, int accumulat
   return hipGetLastError();
 }
 
-// out[j] (+)= sum_i v[i] * W[i*cols + j]: a row vector times a row-major fp32 matrix (64 columns per block, 4 row groups
-// folded through LDS in fixed order).  Used for the v_proj bias gradient, see encoder.hip.
+// out[j] (+)= sum_i v[i] * W[i*cols + j]: a row vector times a row-major fp32 matrix.  Block (x, y) sums row chunk y of 64
+// columns (4 row groups folded through LDS) into partial[y][j]; reduce_partials folds the chunks in fixed order.
+// Used for the v_proj bias gradient, see encoder.hip.  scratch: >= VECMAT_CHUNKS * cols floats.
+constexpr int VECMAT_CHUNKS = 16;
 __global__ __launch_bounds__(256) void vecmat_f32_kernel(const float* __restrict__ v, const float* __restrict__ W, int rows,
-                                                         int cols, float* __restrict__ out, int accumulate) {
+                                                         int cols, float* __restrict__ partial) {
   __shared__ float part[4][64];
   const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jj;
+  const int per = (rows + VECMAT_CHUNKS - 1) / VECMAT_CHUNKS;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
   float s = 0.f;
   if (j < cols)
-    for (int i = rg; i < rows; i += 4) s = fmaf(v[i], W[(size_t)i * cols + j], s);
+    for (int i = r0 + rg; i < r1; i += 4) s = fmaf(v[i], W[(size_t)i * cols + j], s);
   part[rg][jj] = s;
   __syncthreads();
-  if (rg == 0 && j < cols) {
-    const float r = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
-    out[j] = accumulate ? out[j] + r : r;
-  }
+  if (rg == 0 && j < cols) partial[(size_t)blockIdx.y * cols + j] = (part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj]);
 }
-hipError_t vecmat_f32(const float* v, const float* W, int rows, int cols, float* out, int accumulate, hipStream_t s) {
+hipError_t vecmat_f32(const float* v, const float* W, int rows, int cols, float* scratch, float* out, int accumulate,
+                      hipStream_t s) {
   if (rows <= 0 || cols <= 0) return hipSuccess;
-  hipLaunchKernelGGL(vecmat_f32_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, s, v, W, rows, cols, out, accumulate);
-  return hipGetLastError();
+  hipLaunchKernelGGL(vecmat_f32_kernel, dim3((unsigned)((cols + 63) / 64), VECMAT_CHUNKS), dim3(256), 0, s, v, W, rows, cols,
+                     scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return reduce_partials(scratch, VECMAT_CHUNKS, cols, out, cols, accumulate, s);
 }
 
 // ---- position-table bicubic resize (F.interpolate bicubic, align_corners=False, A=-0.75;

@@ -122,7 +122,7 @@ struct Layout {
       w_lnpart = w.take((size_t)layernorm_bwd_blocks(M) * 3 * D * 4);
       w_gsum = w.take(D * 4);        // column sums of the current d hidden_states (bias grad of the GEMM below)
       w_csum = w.take((size_t)((M + 127) / 128) * widest * 4);   // per-row-tile column sums out of a GEMM epilogue
-      w_cspart = w.take((size_t)colsum_chunks(M) * widest * 4);
+      w_cspart = w.take((size_t)(colsum_chunks(M) > 16 ? colsum_chunks(M) : 16) * widest * 4);   // also vecmat_f32's 16 row chunks
       w_dlast = w.take(Mz * D * 4);
       w_hg = w.take((size_t)B * D * es);
       w_hdu = w.take((size_t)B * Ip * es);
@@ -863,7 +863,7 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
     // (One column-sum pass over a third of dqkv instead of all of it: 116 -> ~40 us per block at B = 128.)
     if (gb[0]) RET(bias_grad(ctx, lay, ws, dqkv, 3 * D, M, D, D, gb[0], acc, s));
     if (gb[1] && !acc) CK(hipMemsetAsync(gb[1], 0, (size_t)D * 4, s));
-    if (gb[2]) CK(vecmat_f32(gsum, lw.o_w, D, D, gb[2], acc, s));
+    if (gb[2]) CK(vecmat_f32(gsum, lw.o_w, D, D, reinterpret_cast<float*>(at(ws, lay.w_cspart)), gb[2], acc, s));
   }
   if (d_tap) CK(add_f32(dx, d_tap, dx, (size_t)M * D, s));
   const bool ln1_params = lg.ln1_w || lg.ln1_b;

@@ -73,8 +73,9 @@ int colsum_chunks(int M);
 hipError_t colsum(const void* in, int dtype, int ld, int M, int N, int n_out, float* partial /*[chunks][N]*/,
                   float* out, int accumulate, hipStream_t s);
 hipError_t batch_sum(const float* in, int B, size_t n, float* out, int accumulate, hipStream_t s);
-// out[j] (+)= sum_i v[i] * W[i*cols + j]
-hipError_t vecmat_f32(const float* v, const float* W, int rows, int cols, float* out, int accumulate, hipStream_t s);
+// out[j] (+)= sum_i v[i] * W[i*cols + j]; scratch: >= 16 * cols floats
+hipError_t vecmat_f32(const float* v, const float* W, int rows, int cols, float* scratch, float* out, int accumulate,
+                      hipStream_t s);
 hipError_t pos_resize(const float* table, int g0, float* out, int gh, int gw, int D, hipStream_t s);
 hipError_t pos_resize_bwd(const float* dout, int gh, int gw, float* dtable, int g0, int D, hipStream_t s);
 hipError_t copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
