@@ -113,6 +113,15 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   return fmaf(x * (s * (1.0f - s)), zp, s);
 }
 
+// gelu(x) and d gelu / dx from one sigmoid evaluation (the forward epilogue can save the derivative instead of x)
+__device__ __forceinline__ void gelu_tanh_both(float x, float& a, float& g) {
+  const float x2 = x * x;
+  const float s = gelu_sigmoid(x, x2);
+  const float zp = fmaf(6.0f * SGL_GELU_C * SGL_GELU_A, x2, 2.0f * SGL_GELU_C);
+  a = x * s;
+  g = fmaf(x * (s * (1.0f - s)), zp, s);     // same operations as gelu_tanh_grad
+}
+
 // ---- buffer resources (hardware bounds check: out-of-range loads return 0, stores are dropped) -------
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);

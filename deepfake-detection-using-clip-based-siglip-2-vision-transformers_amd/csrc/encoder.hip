@@ -510,6 +510,7 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
     {
       EpiParams p;
       p.out = (train && l >= first_trainable_block) ? lb + lay.r_u : nullptr;
+      p.gelu_grad_form = (dt == DT_BF16);   // r_u holds gelu'(u) in bf16 mode (the backward only ever needs that)
       p.ldo = Ip;
       p.out2 = lb + lay.r_a;
       p.ldo2 = Ip;
@@ -804,6 +805,7 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
     p.ldo = Ip;
     p.aux = lb + lay.r_u;
     p.ldaux = Ip;
+    p.gelu_grad_form = (dt == DT_BF16);
     if (fuse_cs) {  // deterministic: one row of partial sums per 128-row tile, folded in order below
       CK(hipMemsetAsync(csum, 0, (size_t)((M + 127) / 128) * Ip * 4, s));
       p.colsum = csum;

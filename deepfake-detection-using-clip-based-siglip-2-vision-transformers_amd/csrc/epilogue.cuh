@@ -31,9 +31,11 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       v[j] += b[j];
-      a[j] = gelu_tanh(v[j]);
+      if (p.out && p.gelu_grad_form) gelu_tanh_both(v[j], a[j], v[j]);   // v := gelu'(u)
+      else a[j] = gelu_tanh(v[j]);
     }
-    // the pre-activation u is only read by the backward GELU': inference and frozen blocks pass out == nullptr
+    // the pre-activation u (or gelu'(u), gelu_grad_form) is only read by the backward GELU': inference and frozen blocks
+    // pass out == nullptr
     if (p.out) Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
     Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out2) + (size_t)row * p.ldo2 + col, a);
   } else if constexpr (EPI == EPI_RES_F32) {
@@ -74,7 +76,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
     float u[NV];
     Vec<TOut, NV>::ld(reinterpret_cast<const TOut*>(p.aux) + (size_t)row * p.ldaux + col, u);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] *= gelu_tanh_grad(u[j]);
+    for (int j = 0; j < NV; ++j) v[j] *= p.gelu_grad_form ? u[j] : gelu_tanh_grad(u[j]);
     Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
   } else if constexpr (EPI == EPI_POS_F32) {
     float b[NV], e[NV];

@@ -159,12 +159,17 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
           Vec<float, NV>::st(reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol, v);
         } else if constexpr (EPI == EPI_BIAS_GELU) {
           float a[NV];
+          if (p.out && p.gelu_grad_form) {   // training, derivative form: out := gelu'(u) (EpiParams::gelu_grad_form)
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            v[j] += bias[j];
-            a[j] = gelu_tanh(v[j]);
+            for (int j = 0; j < NV; ++j) gelu_tanh_both(v[j] + bias[j], a[j], v[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+              v[j] += bias[j];
+              a[j] = gelu_tanh(v[j]);
+            }
           }
-          // the pre-activation u is only read by the backward GELU': inference and frozen blocks pass out == nullptr
+          // u / gelu'(u) is only read by the backward GELU': inference and frozen blocks pass out == nullptr
           if (p.out) Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
           Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out2) + (size_t)grow * p.ldo2 + gcol, a);
         } else if constexpr (EPI == EPI_QKV) {
@@ -194,8 +199,13 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
 #pragma unroll
             for (int j = 0; j < NV; ++j) u[j] = uf[j];
           }
+          if (p.gelu_grad_form) {
 #pragma unroll
-          for (int j = 0; j < NV; ++j) v[j] *= gelu_tanh_grad(u[j]);
+            for (int j = 0; j < NV; ++j) v[j] *= u[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] *= gelu_tanh_grad(u[j]);
+          }
           Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
 #pragma unroll
           for (int j = 0; j < NV; ++j) csum[j] += v[j];

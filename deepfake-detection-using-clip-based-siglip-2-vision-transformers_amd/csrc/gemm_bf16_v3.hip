@@ -465,6 +465,7 @@ hipError_t launch_nt7(const bf16* A, int lda, const bf16* B, int ldb, int M, int
 // Returns hipErrorNotSupported when the problem is outside what generation 7 covers (the caller falls back to 6).
 hipError_t gemm_nt7_bf16(const void* A_, int lda, const void* B_, int ldb, int M, int N, int K, int epi, int out_dtype,
                          const EpiParams& p, hipStream_t s) {
+  if (p.gelu_grad_form) return hipErrorNotSupported;   // only generation 6 and the generic epilogue implement it
   const bf16* A = (const bf16*)A_;
   const bf16* B = (const bf16*)B_;
   if (K < 2 * P_BK || M < 8 * P_BM) return hipErrorNotSupported;

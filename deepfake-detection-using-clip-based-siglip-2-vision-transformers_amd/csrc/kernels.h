@@ -39,6 +39,10 @@ struct EpiParams {
   // STORES its column sums at colsum[(m0 / 128) * colsum_ld + col]; the host zeroes the [ceil(M/128)][colsum_ld] buffer
   // first and folds the rows in a fixed order afterwards (reduce_partials)
   int colsum_ld = 0;
+  // EPI_BIAS_GELU / EPI_GELU_BWD pair: when set, the forward stores gelu'(u) in `out` instead of the pre-activation u and
+  // the backward multiplies by the saved value instead of re-evaluating the derivative (two transcendentals per element
+  // less in the backward epilogue, six plain VALU operations more in the forward one); both launches must agree
+  int gelu_grad_form = 0;
   // split-K TN GEMM, deterministic form: split s stores its partial tile at out + s*split_stride (plain stores, ldo = N2)
   // instead of atomically adding into the result; reduce_splits() then sums the slabs in a fixed order
   size_t split_stride = 0;
