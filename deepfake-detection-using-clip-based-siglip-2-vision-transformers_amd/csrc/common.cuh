@@ -47,14 +47,25 @@ template <> struct Elem<bf16> {
 
 // load / store NV (4 or 8) consecutive elements as float; pointers must be NV*sizeof(T)-aligned
 template <typename T, int NV> struct Vec;
+// st_nt / ld_nt: streaming ("nt") cache policy for tensors that are larger than the L2s and touched once per kernel: an
+// epilogue's outputs written with plain stores evict the weight / activation panels the NEXT tiles' main loops are reading
+// (fc1+GELU: 1025 -> 916 us at B = 128 with nontemporal stores alone).
 template <> struct Vec<float, 4> {
   static __device__ __forceinline__ void ld(const float* p, float* v) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
+  static __device__ __forceinline__ void ld_nt(const float* p, float* v) {
+    f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
   static __device__ __forceinline__ void st(float* p, const float* v) {
     f32x4 t = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = t;
+  }
+  static __device__ __forceinline__ void st_nt(float* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
   }
 };
 template <> struct Vec<float, 8> {
@@ -63,6 +74,9 @@ template <> struct Vec<float, 8> {
   }
   static __device__ __forceinline__ void st(float* p, const float* v) {
     Vec<float, 4>::st(p, v); Vec<float, 4>::st(p + 4, v + 4);
+  }
+  static __device__ __forceinline__ void st_nt(float* p, const float* v) {
+    Vec<float, 4>::st_nt(p, v); Vec<float, 4>::st_nt(p + 4, v + 4);
   }
 };
 template <> struct Vec<bf16, 4> {
@@ -77,6 +91,12 @@ template <> struct Vec<bf16, 4> {
     for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i];
     *reinterpret_cast<bf16x4*>(p) = t;
   }
+  static __device__ __forceinline__ void st_nt(bf16* p, const float* v) {
+    bf16x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i];
+    __builtin_nontemporal_store(t, reinterpret_cast<bf16x4*>(p));
+  }
 };
 template <> struct Vec<bf16, 8> {
   static __device__ __forceinline__ void ld(const bf16* p, float* v) {
@@ -89,6 +109,12 @@ template <> struct Vec<bf16, 8> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
     *reinterpret_cast<bf16x8*>(p) = t;
+  }
+  static __device__ __forceinline__ void st_nt(bf16* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+    __builtin_nontemporal_store(t, reinterpret_cast<bf16x8*>(p));
   }
 };
 

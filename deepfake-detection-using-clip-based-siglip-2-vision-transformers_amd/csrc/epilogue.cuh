@@ -24,7 +24,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] += b[j];
     }
-    Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
+    Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
   } else if constexpr (EPI == EPI_BIAS_GELU) {
     float b[NV], a[NV];
     Vec<float, NV>::ld(p.bias + col, b);
@@ -36,15 +36,15 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
     }
     // the pre-activation u (or gelu'(u), gelu_grad_form) is only read by the backward GELU': inference and frozen blocks
     // pass out == nullptr
-    if (p.out) Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
-    Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out2) + (size_t)row * p.ldo2 + col, a);
+    if (p.out) Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
+    Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out2) + (size_t)row * p.ldo2 + col, a);
   } else if constexpr (EPI == EPI_RES_F32) {
     float b[NV], r[NV];
     Vec<float, NV>::ld(p.bias + col, b);
     Vec<float, NV>::ld(p.res + (size_t)row * p.ldr + col, r);
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = r[j] + (v[j] + b[j]);
-    Vec<float, NV>::st(reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + col, v);
+    Vec<float, NV>::st_nt(reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + col, v);
   } else if constexpr (EPI == EPI_QKV) {
     const int dm = p.heads * p.head_dim;
     const int which = col / dm;
@@ -63,21 +63,21 @@ __device__ __forceinline__ void epi_apply(const EpiParams& p, int row, int col, 
     for (int j = 0; j < NV; ++j) v[j] += bb[j];
     TOut* dst = reinterpret_cast<TOut*>(p.out) +
                 ((((size_t)which * p.batch + b) * p.heads + h) * p.tokens + n) * p.head_dim_pad + d;
-    Vec<TOut, NV>::st(dst, v);
+    Vec<TOut, NV>::st_nt(dst, v);
     if (d + NV == p.head_dim) {
       // zero the pad columns [head_dim, head_dim_pad): head_dim % 8 == 0 and head_dim_pad = round_up(head_dim, 16), so the
       // pad is 0 or 8 elements, i.e. whole NV-chunks: vector stores (scalar 2-byte stores here cost the QKV GEMM ~15 %)
       float z[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) z[j] = 0.f;
-      for (int j = p.head_dim; j + NV <= p.head_dim_pad; j += NV) Vec<TOut, NV>::st(dst + (j - d), z);
+      for (int j = p.head_dim; j + NV <= p.head_dim_pad; j += NV) Vec<TOut, NV>::st_nt(dst + (j - d), z);
     }
   } else if constexpr (EPI == EPI_GELU_BWD) {
     float u[NV];
     Vec<TOut, NV>::ld(reinterpret_cast<const TOut*>(p.aux) + (size_t)row * p.ldaux + col, u);
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] *= p.gelu_grad_form ? u[j] : gelu_tanh_grad(u[j]);
-    Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
+    Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)row * p.ldo + col, v);
   } else if constexpr (EPI == EPI_POS_F32) {
     float b[NV], e[NV];
     Vec<float, NV>::ld(p.bias + col, b);

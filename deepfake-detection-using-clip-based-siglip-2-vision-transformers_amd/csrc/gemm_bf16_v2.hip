@@ -156,7 +156,7 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
           const f32x4 r = __builtin_bit_cast(f32x4, pre[pass & 1][q]);
 #pragma unroll
           for (int j = 0; j < NV; ++j) v[j] = r[j] + (v[j] + bias[j]);
-          Vec<float, NV>::st(reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol, v);
+          Vec<float, NV>::st_nt(reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol, v);
         } else if constexpr (EPI == EPI_BIAS_GELU) {
           float a[NV];
           if (p.out && p.gelu_grad_form) {   // training, derivative form: out := gelu'(u) (EpiParams::gelu_grad_form)
@@ -170,8 +170,8 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
             }
           }
           // u / gelu'(u) is only read by the backward GELU': inference and frozen blocks pass out == nullptr
-          if (p.out) Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
-          Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out2) + (size_t)grow * p.ldo2 + gcol, a);
+          if (p.out) Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
+          Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out2) + (size_t)grow * p.ldo2 + gcol, a);
         } else if constexpr (EPI == EPI_QKV) {
           // row / tokens without the ~35-instruction integer division: float reciprocal estimate + one exact correction
           int b = (int)((float)grow * __builtin_amdgcn_rcpf((float)p.tokens));
@@ -181,12 +181,12 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
 #pragma unroll
           for (int j = 0; j < NV; ++j) v[j] += bias[j];
           TOut* dst = reinterpret_cast<TOut*>(p.out) + qkv_c0 + ((size_t)b * p.heads * p.tokens + n) * p.head_dim_pad;
-          Vec<TOut, NV>::st(dst, v);
+          Vec<TOut, NV>::st_nt(dst, v);
           if (qkv_pad) {   // zero the pad columns [head_dim, head_dim_pad): whole NV-chunks (head_dim % 8 == 0, pad = 0 or 8)
             float z[NV];
 #pragma unroll
             for (int j = 0; j < NV; ++j) z[j] = 0.f;
-            for (int k = 1; k <= qkv_pad; ++k) Vec<TOut, NV>::st(dst + k * NV, z);
+            for (int k = 1; k <= qkv_pad; ++k) Vec<TOut, NV>::st_nt(dst + k * NV, z);
           }
         } else if constexpr (EPI == EPI_GELU_BWD) {
           float u[NV];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
 #pragma unroll
             for (int j = 0; j < NV; ++j) v[j] *= gelu_tanh_grad(u[j]);
           }
-          Vec<TOut, NV>::st(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
+          Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
 #pragma unroll
           for (int j = 0; j < NV; ++j) csum[j] += v[j];
         } else {
