@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
-        Vec<TOut, 4>::st(yr + c * 4, o);
+        Vec<TOut, 4>::st_nt(yr + c * 4, o);
       }
     }
     if (lane == 0) {
@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256, (LN_MAXV <= 5 ? 3 : 1)) void ln_bwd_kernel(con
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] += rv[i][j];
         }
-        Vec<float, 4>::st(dxr + c * 4, o);
+        Vec<float, 4>::st_nt(dxr + c * 4, o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ds[i][j] += o[j];
-        if (dx_lp) Vec<TLp, 4>::st(dx_lp + (size_t)row * D + c * 4, o);
+        if (dx_lp) Vec<TLp, 4>::st_nt(dx_lp + (size_t)row * D + c * 4, o);
       }
     }
   }
