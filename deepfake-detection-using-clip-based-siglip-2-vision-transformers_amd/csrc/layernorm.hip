@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    v[i] = (c < nv) ? reinterpret_cast<const f32x4*>(x + (size_t)row * D)[c] : z;
+    v[i] = (c < nv) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (size_t)row * D) + c) : z;
     nx[i] = z;
   }
   const float invD = 1.0f / (float)D;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
       for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + i * 64;
-        if (c < nv) nx[i] = reinterpret_cast<const f32x4*>(x + (size_t)nrow * D)[c];
+        if (c < nv) nx[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (size_t)nrow * D) + c);
       }
     }
     float s = 0.f;
@@ -142,9 +142,9 @@ __global__ __launch_bounds__(256, (LN_MAXV <= 5 ? 3 : 1)) void ln_bwd_kernel(con
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
-        xv[i] = xr[c];
-        dv[i] = *reinterpret_cast<const DyVec*>(dyr + c * 4);
-        if (rr) rv[i] = rr[c];
+        xv[i] = __builtin_nontemporal_load(xr + c);
+        dv[i] = __builtin_nontemporal_load(reinterpret_cast<const DyVec*>(dyr + c * 4));
+        if (rr) rv[i] = __builtin_nontemporal_load(rr + c);
       }
     }
     const float mu = mean[row], rs = rstd[row];
