@@ -22,6 +22,10 @@
 // rocprofv3 FETCH_SIZE on the fc1 shape: the earlier "row panel per XCD" map fetched 6x the algorithmic bytes
 // because the 10 MB weight panel thrashed every 4 MiB L2.  Placement affects speed only.
 #include <stdlib.h>
+#ifdef SGL_TIMELINE
+#include <stdio.h>
+#include <string.h>
+#endif
 
 #include "common.cuh"
 #include "epilogue.cuh"
@@ -426,11 +430,21 @@ __device__ __forceinline__ u32x4 pp_desc(const void* base, uint32_t bytes) {
 //     R2(t):  8 fragment reads (A1 = rows 64-127)                 + DMA units Aq02(t+2), BX(t+2), BY(t+2)
 //     M2(t): A1 x (B0,B1)   32 MFMAs
 // G0 runs R1 in slot 4t, G1 in slot 4t+1.
+// Developer build (make TIMELINE=1, then SGL_TIMELINE=1 in the environment): s_memtime stamps at kernel entry, end of the
+// main loop and end of the epilogue, summed over all workgroups and printed per launch.  This is the tool behind the
+// epilogue findings of DESIGN.md section 8c (loads queued behind stores; fc1's main loop slowed by its own output traffic).
+#ifdef SGL_TIMELINE
+__device__ unsigned long long g_nt6_tl[4];
+#define SGL_TL_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define SGL_TL_STAMP(v)
+#endif
 template <int EPI, typename TOut>
 __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict__ A, int lda,
                                                           const bf16* __restrict__ B, int ldb, int M, int N, int K,
                                                           int tiles_m, int tiles_n, int band_h, EpiParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SGL_TL_STAMP(tl0);
   const int ntiles = tiles_m * tiles_n;
   int tile_m, tile_n;
   if (band_h < 0) {
@@ -545,7 +559,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict
   if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
   if (p.atomic == 77) return;   // developer experiment (SGL_NT6_SKIP_EPI): main loop only
+  SGL_TL_STAMP(tl1);
   store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
+#ifdef SGL_TIMELINE
+  SGL_TL_STAMP(tl2);
+  if (t == 0) {
+    atomicAdd(&g_nt6_tl[0], tl1 - tl0);
+    atomicAdd(&g_nt6_tl[1], tl2 - tl1);
+    atomicAdd(&g_nt6_tl[2], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -788,6 +811,18 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
     if (skip_epi && EPI != EPI_F32) pp.atomic = 77;
     hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid6), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
                        tiles_m, tiles_n, band_h, pp);
+#ifdef SGL_TIMELINE
+    if (getenv("SGL_TIMELINE")) {   // synchronises: measurement builds only
+      unsigned long long h[4];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nt6_tl), sizeof(h));
+      if (h[2])
+        fprintf(stderr, "[timeline] gemm_nt6 EPI %d M=%d N=%d K=%d: %llu tiles, main loop %.0f, epilogue %.0f cycles per tile\n", EPI, M,
+                N, K, h[2], (double)h[0] / h[2], (double)h[1] / h[2]);
+      memset(h, 0, sizeof(h));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nt6_tl), h, sizeof(h));
+    }
+#endif
     return hipGetLastError();
   }
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
