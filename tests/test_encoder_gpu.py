@@ -267,3 +267,40 @@ def test_inference_mode_and_autocast_contexts(pkg, hiplib):
         c = model(pixel_values=x.half()).pooler_output          # fp16 pixels as an autocast pipeline may hand them over
     assert torch.equal(a, b) and a.dtype == torch.float32
     assert torch.allclose(a, c, atol=2e-2)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_qkv_bias_gradients_follow_the_identities_the_backward_uses(mode):
+    """The backward never sums dK or dV over the tokens (csrc/encoder.hip): the k_proj bias gradient is written as exact
+    zeros (softmax is invariant to a per-query shift of the scores) and the v_proj bias gradient is colsum(dY) * W_o, with
+    colsum(dY) the out_proj bias gradient; only dQ gets a column-sum pass.  Checked here against autograd on the CPU oracle
+    for every block of the shape-hostile config (d_h = 72, two heads, N = 9)."""
+    import __graft_entry__ as entry
+    pkg, oracle = entry.load_package(), entry.load_oracle()
+    cfg = pkg.get_config("hostile")
+    sd0 = pkg.weights.seeded_state_dict(cfg, seed=23)
+    x = pkg.weights.seeded_pixels(3, 42, 42, seed=7)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    out = oracle.vision_forward(x, ref, cfg, False, True)
+    w = torch.cos(torch.arange(out["pooler_output"].numel(), dtype=torch.float32).reshape(out["pooler_output"].shape) * 0.31)
+    ((out["pooler_output"] * w).sum() + 0.05 * out["last_hidden_state"].square().sum()).backward()
+
+    model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
+    model.load_state_dict(sd0)
+    model = model.cuda()
+    o = model(pixel_values=x.cuda(), interpolate_pos_encoding=True)
+    ((o.pooler_output * w.cuda()).sum() + 0.05 * o.last_hidden_state.square().sum()).backward()
+    got = dict(model.named_parameters())
+    rtol = 3.5e-6 if mode == "fp32" else 2.3e-2        # 2x the measured 1.6e-6 / 1.15e-2 (relative to the tensor's max)
+    for l in range(cfg.num_hidden_layers):
+        pre = f"encoder.layers.{l}.self_attn."
+        for which in ("q_proj", "v_proj"):
+            r = ref[pre + which + ".bias"].grad
+            g = got[pre + which + ".bias"].grad.cpu()
+            err = (g - r).abs().max().item() / (r.abs().max().item() + 1e-30)
+            print(f"[qkv bias {mode}] layer {l} {which}: rel err {err:.2e}")
+            assert err <= rtol, (l, which, err)
+        gk = got[pre + "k_proj.bias"].grad
+        assert gk is not None and torch.count_nonzero(gk).item() == 0          # exact zeros by construction
+        rk = ref[pre + "k_proj.bias"].grad.abs().max().item()
+        assert rk <= 1e-4 * ref[pre + "q_proj.bias"].grad.abs().max().item()   # and the reference agrees up to rounding noise
