@@ -45,7 +45,50 @@ def parse():
                     help="launches per kernel for the roofline / breakdown legs; 0 skips them (clean rocprofv3 traces)")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="skip the optimizer-step and full-train-step legs (clean rocprofv3 traces of the timed step)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary metrics of SURVEY.md 8d (batch sweep, base-patch16-224 B=256, frozen prefix)")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: gradient exchange format (ddp.GradBucketReducer)")
+    ap.add_argument("--max-buckets", type=int, default=8, help="N > 1: gradient chunks (= collectives) per step")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS), i.e. the CUs its kernels take from the GEMMs")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the train_step_with_optimizer leg")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (how the driver calls it): start the N
+    ranks as CHILD processes through torch.distributed.run.  This parent has made no GPU call (importing torch does not
+    initialise HIP) and never execs; it relays rank 0's single JSON line and returns non-zero if any rank failed."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = []
+    for ln in proc.stdout:                      # stderr is inherited: progress lines stream through as they come
+        if ln.startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench] expected exactly one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    return rc
 
 
 def gemm_kernel_roofline(pkg, cfg, batch, res, reps):
@@ -223,25 +266,79 @@ def step_breakdown(pkg, cfg, batch, res, reps, nt_per_shape):
                     f"({L} blocks); LayerNorm rows are x2 (two per block)"}
 
 
-def full_train_step(pkg, model, x, steps=3):
-    """fwd + bwd + FusedAdamW (clip + AdamW + bf16 weight-shadow writes in ONE pass: no separate re-cast) per step."""
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def full_train_step(pkg, model, x, steps=10, warmup=2):
+    """fwd + bwd + FusedAdamW (clip + AdamW + bf16 weight-shadow writes in ONE pass: no separate re-cast) per step.
+
+    Every step is bracketed by HIP events on the launch stream and reported individually (min / median / max), with the
+    phases inside it (forward+backward, optimizer, zero_grad) and what could make a step slow for reasons that are not
+    kernels: caching-allocator traffic (`num_device_alloc` = hipMalloc calls, `num_alloc_retries`) and whether FusedAdamW
+    rebuilt and re-uploaded its device table inside the timed region.  Round 2's driver run showed 503.7 ms here against
+    304 ms of fwd+bwd with 1 warm-up and 3 wall-clock-timed steps: the first optimizer step allocates 3.4 GB of AdamW state
+    out of the cached 87 GB activation block the previous backward had just freed, so the NEXT step's activation arena
+    needs a fresh hipMalloc of 87 GB - a one-off that a 3-step mean spreads over the figure.  Two warm-ups absorb it."""
     params = [p for p in model.parameters() if p.requires_grad]
     opt = pkg.FusedAdamW(params, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0).attach_encoder(model)
+    st = torch.cuda.current_stream()
+    ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    marks = []
+    uploads = [0]
+    orig_tables = opt._device_tables
 
-    def step():
+    def counted_tables(lib, ents, dev):
+        key0 = (opt._table_key, opt._aux_key)
+        out = orig_tables(lib, ents, dev)
+        uploads[0] += int((opt._table_key, opt._aux_key) != key0)
+        return out
+    opt._device_tables = counted_tables
+
+    def step(record):
+        e = [ev() for _ in range(4)]
+        e[0].record(st)
         out = model(pixel_values=x, interpolate_pos_encoding=True)
         out.pooler_output.square().mean().backward()
+        e[1].record(st)
         opt.step()
+        e[2].record(st)
         opt.zero_grad(set_to_none=True)
-    step()
+        e[3].record(st)
+        if record:
+            marks.append(e)
+
+    def mem():
+        s_ = torch.cuda.memory_stats()
+        return {k: int(s_.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    m_before_warm = mem()
+    for _ in range(warmup):
+        step(False)
     torch.cuda.synchronize()
+    up_warm, uploads[0] = uploads[0], 0
+    m0 = mem()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        step(True)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"images_per_sec": round(x.shape[0] / dt, 2), "ms_per_step": round(dt * 1e3, 2),
-            "what": "forward + backward + FusedAdamW(max_grad_norm) with the weight shadows written by the optimizer"}
+    wall = (time.perf_counter() - t0) / steps
+    m1 = mem()
+    per = [e[0].elapsed_time(e[3]) for e in marks]
+    fb = [e[0].elapsed_time(e[1]) for e in marks]
+    op = [e[1].elapsed_time(e[2]) for e in marks]
+    med = _median(per)
+    return {"images_per_sec": round(x.shape[0] / (med * 1e-3), 2), "ms_per_step": round(med, 2),
+            "ms_per_step_min": round(min(per), 2), "ms_per_step_max": round(max(per), 2),
+            "ms_per_step_wall_mean": round(wall * 1e3, 2), "per_step_ms": [round(v, 1) for v in per],
+            "fwd_bwd_ms_median": round(_median(fb), 2), "optimizer_ms_median": round(_median(op), 3),
+            "timed_steps": steps, "warmup_steps": warmup,
+            "allocator_delta_timed": {k: m1[k] - m0[k] for k in m0},
+            "allocator_delta_warmup": {k: m0[k] - m_before_warm[k] for k in m0},
+            "optimizer_table_uploads": {"warmup": up_warm, "timed": uploads[0]},
+            "what": "forward + backward + FusedAdamW(max_grad_norm) with the weight shadows written by the optimizer; "
+                    "HIP events per step on the launch stream, median reported"}
 
 
 def optimizer_step_roofline(pkg, model, x, reps=10):
@@ -320,7 +417,8 @@ def host_cores() -> int:
 
 def cpu_baseline(pkg, cfg, res, steps):
     """The CPU oracle (port of the HF path, validated against HF in tests/) timed on this box's host cores, on a
-    bounded sample of the same workload (batch 2, a few steps)."""
+    bounded sample of the same workload (batch 2, a few steps): fp32 (`value`) and, as SURVEY.md 8d asks, under
+    torch.autocast("cpu", bfloat16) - the precision the reference trains in (Siglip2sidafrozen.py:1375)."""
     oracle = entry.load_oracle()
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -330,7 +428,7 @@ def cpu_baseline(pkg, cfg, res, steps):
 
     def step(xb):
         out = oracle.vision_forward(xb, sd, cfg, False, True)
-        out["pooler_output"].square().mean().backward()
+        out["pooler_output"].float().square().mean().backward()
         for v in sd.values():
             v.grad = None
     print(f"[bench] cpu_baseline: warm-up on {cores} cores ...", file=sys.stderr, flush=True)
@@ -341,54 +439,65 @@ def cpu_baseline(pkg, cfg, res, steps):
         print(f"[bench] cpu_baseline: step {i + 1}/{steps} at {time.perf_counter() - t0:.1f} s", file=sys.stderr,
               flush=True)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{cfg_name_of(cfg)} fp32 oracle, batch {B}, {steps} timed fwd+bwd steps after a 1-image warm-up"}
+    out = {"value": round(B / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"{cfg_name_of(cfg)} fp32 oracle, batch {B}, {steps} timed fwd+bwd steps after a 1-image warm-up"}
+    # bf16 autocast leg, bounded: a CPU without native bf16 dot products runs oneDNN's reference path (10-100x slower
+    # than fp32), so the cost is estimated from one GEMM of the step's shape first
+    a = torch.randn(B * (res // cfg.patch_size) ** 2, cfg.hidden_size)
+    w = torch.randn(cfg.intermediate_size, cfg.hidden_size)
+
+    def t_mm(a_, w_):
+        a_ @ w_.t()
+        t = time.perf_counter()
+        for _ in range(3):
+            a_ @ w_.t()
+        return (time.perf_counter() - t) / 3
+    ratio = t_mm(a.bfloat16(), w.bfloat16()) / t_mm(a, w)
+    est = dt * ratio
+    if est > 45.0:
+        out["bf16_autocast"] = {"value": None, "note": f"skipped: a bf16 GEMM of the step's shape is {ratio:.1f}x slower "
+                                f"than fp32 on this host (no native bf16 dot product), one step would take ~{est:.0f} s"}
+        return out
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        step(x[:1])
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(x)
+            print(f"[bench] cpu_baseline (bf16 autocast): step {i + 1}/{steps} at {time.perf_counter() - t0:.1f} s",
+                  file=sys.stderr, flush=True)
+        dtb = (time.perf_counter() - t0) / steps
+    out["bf16_autocast"] = {"value": round(B / dtb, 4), "unit": "images/sec",
+                            "sample": f"same oracle under torch.autocast('cpu', bfloat16), batch {B}, {steps} timed steps"}
+    return out
 
 
 def cfg_name_of(cfg):
     return f"D{cfg.hidden_size}-I{cfg.intermediate_size}-L{cfg.num_hidden_layers}-p{cfg.patch_size}@{cfg.image_size}"
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    # rehearsal hooks (tests/test_bench_multiproc_gpu.py): every rank on one device over gloo; the driver never sets them
-    backend = os.environ.get("SGL_BENCH_BACKEND", "nccl")
-    if os.environ.get("SGL_BENCH_ONE_DEVICE") == "1":
-        local = 0
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    pkg = entry.load_package()
-    pkg.lib.load()
-    cfg = pkg.get_config(args.config)
-    res = args.res or cfg.image_size
-    dev = torch.device("cuda", local)
-
-    model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=args.mode)
+def build_model(pkg, cfg, mode, dev, freeze_below=0):
+    model = pkg.SiglipVisionModelHIP(cfg, compute_dtype=mode)
     model.load_state_dict(pkg.weights.seeded_state_dict(cfg, seed=0))
     model = model.to(dev)
-    if args.freeze_below > 0:
-        for p in model.vision_model.embeddings.parameters():
-            p.requires_grad = False
-        for i, layer in enumerate(model.vision_model.encoder.layers):
-            for p in layer.parameters():
-                p.requires_grad = i >= args.freeze_below
-    if world > 1:
-        pkg.ddp.broadcast_parameters(model, src=0)
-        pkg.GradBucketReducer().attach(model)
-    x = pkg.weights.seeded_pixels(args.batch, res, res, seed=1234 + rank).to(dev)
+    set_frozen_prefix(model, freeze_below)
+    return model
+
+
+def set_frozen_prefix(model, k):
+    """Siglip2sidafrozen.py:757-768: embeddings and blocks < k frozen (k = 0: everything trains)."""
+    for p in model.vision_model.embeddings.parameters():
+        p.requires_grad = k == 0
+    for i, layer in enumerate(model.vision_model.encoder.layers):
+        for p in layer.parameters():
+            p.requires_grad = i >= k
+
+
+def timed_steps(model, x, warmup, steps, world=1):
+    """W untimed steps, then K steps bracketed by barrier + synchronize on both sides (the contract's wall clock), with a
+    HIP event between steps on the launch stream for the per-step distribution.  Returns (seconds, [ms per step])."""
     params = [p for p in model.parameters()]
     trainable = [p for p in params if p.requires_grad]
+    st = torch.cuda.current_stream()
 
     def step():
         # an optimizer step happened: every trainable parameter changed, so its bf16 shadows are re-cast in this step
@@ -400,35 +509,139 @@ def main():
         for p in params:
             p.grad = None
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record(st)
+    for i in range(steps):
         step()
+        evs[i + 1].record(st)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def frozen_prefix_flops(cfg, gh, k):
+    """fwd + 2*[(L-k)*layer + head]."""
+    Nn, D, I, L = gh * gh, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    layer = 8 * Nn * D * D + 4 * Nn * Nn * D + 4 * Nn * D * I
+    head = 4 * Nn * D * D + 4 * D * D + 4 * Nn * D + 4 * D * I
+    fwd = cfg.fwd_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
+    return fwd + 2 * ((L - min(k, L)) * layer + head)
+
+
+def secondary_metrics(pkg, cfg, model, res, dev, batch):
+    """SURVEY.md 8d's secondary figures, measured in the same run (N = 1), HIP-event median over a few steps each:
+    per-GPU batch sweep, the frozen-prefix SID configuration (blocks >= 21 trainable), the video configuration (frames/s =
+    images/s at B = 32*b; clips/s = /32) and BASELINE config 2 (base-patch16-224, B = 256)."""
+    out = {}
+    gh = res // cfg.patch_size
+    tf = cfg.train_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
+    sweep = {}
+    for b in (16, 32, 64):
+        if b >= batch:
+            continue
+        xb = pkg.weights.seeded_pixels(b, res, res, seed=99).to(dev)
+        _, per = timed_steps(model, xb, 2, 5)
+        ips = b / (_median(per) * 1e-3)
+        sweep[str(b)] = {"images_per_sec": round(ips, 1), "step_mfma_frac": round(ips * tf / PEAK_BF16_DENSE, 4)}
+        del xb
+    out["batch_sweep"] = sweep
+    k = cfg.num_hidden_layers - 6
+    if k > 0:
+        set_frozen_prefix(model, k)
+        xb = pkg.weights.seeded_pixels(batch, res, res, seed=1234).to(dev)
+        _, per = timed_steps(model, xb, 2, 5)
+        ips = batch / (_median(per) * 1e-3)
+        out["frozen_prefix"] = {"what": f"embeddings + blocks < {k} frozen (Siglip2sidafrozen.py:757-768), B={batch}",
+                                "images_per_sec": round(ips, 1),
+                                "step_mfma_frac": round(ips * frozen_prefix_flops(cfg, gh, k) / PEAK_BF16_DENSE, 4)}
+        set_frozen_prefix(model, 0)
+        del xb
+    return out
+
+
+def base224_metric(pkg, dev):
+    cfg = pkg.get_config("base-patch16-224")
+    model = build_model(pkg, cfg, "bf16", dev)
+    xb = pkg.weights.seeded_pixels(256, 224, 224, seed=1234).to(dev)
+    _, per = timed_steps(model, xb, 3, 8)
+    ips = 256 / (_median(per) * 1e-3)
+    tf = cfg.train_flops_per_image(224, 224)
+    return {"what": "BASELINE config 2: base-patch16-224 full fine-tune fwd+bwd, bf16, B=256",
+            "images_per_sec": round(ips, 1), "ms_per_step": round(_median(per), 2),
+            "step_mfma_frac": round(ips * tf / PEAK_BF16_DENSE, 4)}
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal hooks (tests/test_bench_multiproc_gpu.py): every rank on one device over gloo; the driver never sets them
+    backend = os.environ.get("SGL_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGL_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    torch.cuda.set_device(local)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    pkg = entry.load_package()
+    pkg.lib.load()
+    cfg = pkg.get_config(args.config)
+    res = args.res or cfg.image_size
+    dev = torch.device("cuda", local)
+
+    model = build_model(pkg, cfg, args.mode, dev, args.freeze_below)
+    reducer = None
+    if world > 1:
+        pkg.ddp.broadcast_parameters(model, src=0)
+        reducer = pkg.GradBucketReducer(wire=args.wire, max_buckets=args.max_buckets).attach(model)
+        reducer.time_exposed = True
+    x = pkg.weights.seeded_pixels(args.batch, res, res, seed=1234 + rank).to(dev)
+
+    if reducer is not None:     # warm-up first, then measure only the timed region's exposed waits
+        dt_w, _ = timed_steps(model, x, args.warmup, 0, world)
+        reducer.exposed_ms()
+        dt, per = timed_steps(model, x, 0, args.steps, world)
+    else:
+        dt, per = timed_steps(model, x, args.warmup, args.steps, world)
+    my_rate = args.batch * args.steps / dt
+    rates = [my_rate]
+    exposed = reducer.exposed_ms() if reducer is not None else []
+    exposed_per_step = sum(exposed) / max(1, args.steps)
+    if world > 1:
+        t = torch.tensor([dt, my_rate, exposed_per_step], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        dt = max(a[0].item() for a in allt)
+        rates = [a[1].item() for a in allt]
+        exposed_per_step = max(a[2].item() for a in allt)
     ms_per_step = dt / args.steps * 1e3
     images = args.batch * world * args.steps
     value = images / dt
     gh = res // cfg.patch_size
     train_flops = cfg.train_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
-    if args.freeze_below > 0:  # fwd + 2*[(L-k)*layer + head]
-        Nn, D, I, L = gh * gh, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-        layer = 8 * Nn * D * D + 4 * Nn * Nn * D + 4 * Nn * D * I
-        head = 4 * Nn * D * D + 4 * D * D + 4 * Nn * D + 4 * D * I
-        fwd = cfg.fwd_flops_per_image(gh * cfg.patch_size, gh * cfg.patch_size)
-        train_flops = fwd + 2 * ((L - min(args.freeze_below, L)) * layer + head)
+    if args.freeze_below > 0:
+        train_flops = frozen_prefix_flops(cfg, gh, args.freeze_below)
 
     line = {
         "metric": ("images/sec (train fwd+bwd) SigLIP-2-so400m@384 bf16"
@@ -443,7 +656,20 @@ def main():
                    "tokens_per_image": gh * gh, "parallelism": f"dp{world}"},
         "step_mfma_frac": round(value / world * train_flops / PEAK_BF16_DENSE, 4),
         "train_tflop_per_image": round(train_flops / 1e12, 4),
+        "ms_per_step_events": {"median": round(_median(per), 3), "min": round(min(per), 3), "max": round(max(per), 3),
+                               "note": "rank 0, HIP events between steps on the launch stream"},
+        "video_equivalent": {"frames_per_sec": round(value, 2), "clips_per_sec_32_frames": round(value / 32, 3),
+                             "note": "BASELINE config 5: a clip is 32 frames through the same encoder (hidf_video_"
+                                     "classifier.py:299-320); per-GPU batch = 32*b frames"},
     }
+    if world > 1:
+        line["ranks_seen"] = dist.get_world_size()
+        line["per_rank_images_per_sec"] = [round(r, 2) for r in rates]
+        line["exposed_comm_ms"] = round(exposed_per_step, 3)
+        line["wire"] = args.wire
+        line["collectives_per_step"] = reducer.collectives_issued // max(1, args.steps + args.warmup)
+        line["backend"] = backend
+        line["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     if rank == 0:
         print(f"[bench] {value:.1f} images/s, {ms_per_step:.1f} ms/step; measuring kernel roofline + CPU baseline ...",
               file=sys.stderr, flush=True)
@@ -453,12 +679,18 @@ def main():
                 if args.mode == "bf16":
                     line["step_breakdown"] = step_breakdown(pkg, cfg, args.batch, res, max(3, args.kernel_reps // 4),
                                                             line["roofline"]["per_shape"])
+            if not args.no_secondary and args.mode == "bf16" and args.freeze_below == 0:
+                line["secondary"] = secondary_metrics(pkg, cfg, model, res, dev, args.batch)
             if not args.no_optimizer:
                 line["optimizer_step"] = optimizer_step_roofline(pkg, model, x)
                 if args.freeze_below == 0:
-                    line["train_step_with_optimizer"] = full_train_step(pkg, model, x)
+                    line["train_step_with_optimizer"] = full_train_step(pkg, model, x, steps=args.train_steps)
             del model
             torch.cuda.empty_cache()
+            if not args.no_secondary and args.mode == "bf16" and args.config == "so400m-patch14-384" \
+                    and args.freeze_below == 0:
+                line.setdefault("secondary", {})["base_patch16_224_B256"] = base224_metric(pkg, dev)
+                torch.cuda.empty_cache()
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(pkg, cfg, res, args.cpu_steps)
         print(json.dumps(line), flush=True)

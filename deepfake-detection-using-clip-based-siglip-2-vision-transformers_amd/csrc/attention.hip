@@ -18,7 +18,7 @@
 // 14·N²·dh; the extra recompute buys determinism and no dQ atomics).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {
@@ -732,6 +732,7 @@ hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out
   return hipErrorInvalidValue;
 }
 
-size_t attn_bwd_scratch_bytes(int, int B, int H, int N, int, int) { return (size_t)B * H * N * sizeof(float); }
+// delta_scratch of attn_bwd: {-lse*log2e, -delta*scale} PAIRS per (batch, head, query) = 2*B*H*N floats (since round 2)
+size_t attn_bwd_scratch_bytes(int, int B, int H, int N, int, int) { return (size_t)2 * B * H * N * sizeof(float); }
 
 }  // namespace sgl

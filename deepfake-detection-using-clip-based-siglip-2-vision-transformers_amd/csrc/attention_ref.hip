@@ -2,7 +2,7 @@
 // query row (forward, dQ) or per key row (dK, dV).  Deterministic (no atomics).  Follows the eager path of
 // TF:models/siglip/modeling_siglip.py:227-247.  Not a performance path; the bf16 path is attention.hip.
 // q,k,v head-major [B][H][N][DP] fp32; out / dout token-major [B*N][H*dh]; dqkv token-major [B*N][3*H*dh].
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {

@@ -1,6 +1,6 @@
 // HBM-bound helper kernels around the encoder GEMMs (gfx950): patch gather (im2col), weight-shadow casts,
 // bias-gradient column sums, position-table bicubic resize, and the 1-query attention-pool head.
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {

@@ -8,7 +8,7 @@
 //   EPI_BIAS_GELU fc1 bias + gelu_pytorch_tanh                              :319-320
 //   EPI_POS_F32   patch conv bias + position embedding add                  :178-184
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {

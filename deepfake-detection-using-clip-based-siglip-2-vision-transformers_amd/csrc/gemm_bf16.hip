@@ -21,8 +21,8 @@
 // Roofline: MFMA-bound (arithmetic intensity K/2... >> machine balance); algorithmic FLOPs = 2*M*N*K.
 #include <stdlib.h>
 
-#include "common.cuh"
-#include "epilogue.cuh"
+#include "common.hip.h"
+#include "epilogue.hip.h"
 #include "kernels.h"
 
 namespace sgl {
@@ -318,6 +318,7 @@ hipError_t gemm_nt2_bf16(const void* A, int lda, const void* B, int ldb, int M, 
                          const EpiParams& p, hipStream_t s);
 hipError_t gemm_tn2_bf16(const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int m_per,
                          int splits, const EpiParams& p, hipStream_t s);
+#ifdef SGL_AB   // developer A/B build (make AB=1): the measured-slower generations 7 / 8 and the "generation 1 everywhere" switch
 // persistent generation 7 (gemm_bf16_v3.hip); hipErrorNotSupported = outside its envelope, fall back to generation 6
 hipError_t gemm_nt7_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, int out_dtype,
                          const EpiParams& p, hipStream_t s);
@@ -333,6 +334,9 @@ static int gemm_generation() {
   }
   return gen;
 }
+#else
+static inline int gemm_generation() { return 2; }
+#endif
 static bool g_attr_done = false;
 
 template <int EPI, typename TOut>
@@ -357,8 +361,9 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
   if (gemm_generation() != 1 && M >= 2048 && N >= 256) {
-    // generation 7 (persistent tile loop, gemm_bf16_v3.hip) is opt-in: measured equal-or-slower than generation 6 on
-    // the encoder's shapes (negative results) — kept for A/B runs: SGL_GEMM_GEN=7
+#ifdef SGL_AB
+    // generation 7 (persistent tile loop, gemm_bf16_v3.hip): measured equal-or-slower than generation 6 on the encoder's
+    // shapes (negative results); A/B build only: SGL_GEMM_GEN=7
     static const bool gen7 = getenv("SGL_GEMM_GEN") && atoi(getenv("SGL_GEMM_GEN")) == 7;
     if (gen7) {
       const hipError_t e = gemm_nt7_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
@@ -369,6 +374,7 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
       const hipError_t e = gemm_nt8_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
       if (e != hipErrorNotSupported) return e;
     }
+#endif
     return gemm_nt2_bf16(A_, lda, B_, ldb, M, N, K, epi, out_dtype, p, s);
   }
   const bf16* A = (const bf16*)A_;

@@ -1,9 +1,9 @@
 // bf16 MFMA GEMMs for gfx950 on a 256x256 output tile, K-step 64, 512 threads = 8 waves, operands streamed
 // global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no VGPR staging), two LDS stages
-// (2 x 64 KiB).  Two main-loop generations share the images, tile order and epilogues:
-//   nt6 / tn6 (default): anti-phase wave groups, four barrier-separated slots per K-step (see the comment above them)
-//   nt2 / tn2 (SGL_GEMM_GEN=2): one barrier per K-step, the DMA for step t+1 is issued right after the barrier that
-//                               retires step t's DMA and runs under step t's 64 MFMAs per wave
+// (2 x 64 KiB).  Main loops (they share the images, tile order and epilogues):
+//   nt6 / tn6: anti-phase wave groups, four barrier-separated slots per K-step (see the comment above them)
+//   nt2 / tn2: developer A/B build only (make AB=1, SGL_GEMM_GEN=2): one barrier per K-step, the DMA for step t+1 is
+//              issued right after the barrier that retires step t's DMA and runs under step t's 64 MFMAs per wave
 //
 //   nt : C[M,N]   = A[M,K] · B[N,K]ᵀ           (forward projections, dX with transposed weight shadows)
 //   tn : C[N1,N2] (+)= Σ_m A[m,N1] · B[m,N2]    (dW; token index is the MFMA k index via ds_read_b64_tr_b16)
@@ -27,8 +27,8 @@
 #include <string.h>
 #endif
 
-#include "common.cuh"
-#include "epilogue.cuh"
+#include "common.hip.h"
+#include "epilogue.hip.h"
 #include "kernels.h"
 
 namespace sgl {
@@ -242,6 +242,7 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
   }
 }
 
+#ifdef SGL_AB   // generation 2 (developer A/B build only: make AB=1)
 // Compile-time interleave for one K-step: READS LDS reads per fragment (1 = ds_read_b128, 2 = two ds_read_b64_tr_b16).
 // prologue 7 fragments (4 B + 3 A), then 16 x {4 MFMA, prefetch of A[f+3] (+ one B fragment of the 2nd k-half at f=3..6)}
 template <int READS, int F>
@@ -258,6 +259,8 @@ __device__ __forceinline__ void sched_pipeline() {
   sched_step<READS, 8>();  sched_step<READS, 9>();  sched_step<READS, 10>(); sched_step<READS, 11>();
   sched_step<READS, 12>(); sched_step<READS, 13>(); sched_step<READS, 14>(); sched_step<READS, 15>();
 }
+
+#endif  // SGL_AB
 
 // blockIdx -> work unit.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 labels the XCD group), each
 // with a private 4 MiB L2.  XCD x takes the CONTIGUOUS chunk [x*per, (x+1)*per) of a locality-ordered unit list, so
@@ -292,6 +295,7 @@ __device__ __forceinline__ bool tile_of_local(int xcd, int v, int tiles_m, int t
   return true;
 }
 
+#ifdef SGL_AB
 // ------------------------------------------------------------------------------------------------------
 template <int EPI, typename TOut>
 __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict__ A, int lda,
@@ -380,6 +384,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_kernel(const bf16* __restrict
   }
   store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
 }
+
+#endif  // SGL_AB
 
 // ------------------------------------------------------------------------------------------------------
 // Anti-phase ("ping-pong") main loops, generation 6 (default).  The two wave groups of the workgroup (G0 = waves
@@ -558,7 +564,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt6_kernel(const bf16* __restrict
   }
   if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
-  if (p.atomic == 77) return;   // developer experiment (SGL_NT6_SKIP_EPI): main loop only
+#ifdef SGL_TIMELINE
+  if (p.atomic == 77) return;   // developer build only (SGL_NT6_SKIP_EPI): main loop without its epilogue
+#endif
   SGL_TL_STAMP(tl1);
   store_tile256<EPI, TOut>(smem, acc, wr, wc, lane, t, m0, n0, M, N, p);
 #ifdef SGL_TIMELINE
@@ -681,6 +689,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn6_kernel(const bf16* __restrict
   store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, pq);
 }
 
+#ifdef SGL_AB
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict__ A, int lda,
                                                           const bf16* __restrict__ B, int ldb, int Mred, int N1, int N2,
@@ -774,21 +783,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(const bf16* __restrict
   store_tile256<EPI_F32, float>(smem, acc, wr, wc, lane, t, n1_0, n2_0, N1, N2, pq);
 }
 
+#endif  // SGL_AB
+
 // ------------------------------------------------------------------------------------------------------
 template <int EPI, typename TOut>
 static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int M, int N, int K, const EpiParams& p,
                              hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt2_kernel<EPI, TOut>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
   const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + T_BN - 1) / T_BN;
   const int grid = ((tiles_m * tiles_n + 7) / 8) * 8;
+#ifdef SGL_AB
   static const int gen = getenv("SGL_GEMM_GEN") ? atoi(getenv("SGL_GEMM_GEN")) : 6;
-  if (gen != 2) {
+  if (gen == 2) {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt2_kernel<EPI, TOut>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
+                       tiles_n, p);
+    return hipGetLastError();
+  }
+#endif
+  {
     static bool attr6 = false;
     if (!attr6) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt6_kernel<EPI, TOut>),
@@ -806,9 +824,11 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
     const int band_h = band_env != 0 ? band_env : -8;
     int grid6 = grid;
     if (band_h < 0) grid6 = 8 * (((tiles_m + 7) / 8) * tiles_n);   // 8 XCDs x the largest per-XCD tile count
-    static const bool skip_epi = getenv("SGL_NT6_SKIP_EPI") != nullptr;
     EpiParams pp = p;
+#ifdef SGL_TIMELINE   // measurement builds only (make TIMELINE=1): the product library never skips an epilogue
+    static const bool skip_epi = getenv("SGL_NT6_SKIP_EPI") != nullptr;
     if (skip_epi && EPI != EPI_F32) pp.atomic = 77;
+#endif
     hipLaunchKernelGGL((gemm_nt6_kernel<EPI, TOut>), dim3(grid6), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K,
                        tiles_m, tiles_n, band_h, pp);
 #ifdef SGL_TIMELINE
@@ -825,9 +845,6 @@ static hipError_t launch_nt2(const bf16* A, int lda, const bf16* B, int ldb, int
 #endif
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((gemm_nt2_kernel<EPI, TOut>), dim3(grid), dim3(512), T_LDS, s, A, lda, B, ldb, M, N, K, tiles_m,
-                     tiles_n, p);
-  return hipGetLastError();
 }
 
 hipError_t gemm_nt2_bf16(const void* A_, int lda, const void* B_, int ldb, int M, int N, int K, int epi, int out_dtype,
@@ -850,30 +867,32 @@ hipError_t gemm_nt2_bf16(const void* A_, int lda, const void* B_, int ldb, int M
 
 hipError_t gemm_tn2_bf16(const void* A_, int lda, const void* B_, int ldb, int Mred, int N1, int N2, int m_per,
                          int splits, const EpiParams& p, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
   const int tiles_1 = (N1 + T_BM - 1) / T_BM, tiles_2 = (N2 + T_BN - 1) / T_BN;
   const int grid = ((tiles_1 * tiles_2 * splits + 7) / 8) * 8;
+#ifdef SGL_AB
   static const int gen = getenv("SGL_GEMM_GEN") ? atoi(getenv("SGL_GEMM_GEN")) : 6;
   static const int tngen = getenv("SGL_TN_GEN") ? atoi(getenv("SGL_TN_GEN")) : gen;
-  if (tngen != 2) {
-    static bool attr6 = false;
-    if (!attr6) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn6_kernel),
+  if (tngen == 2) {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
       if (e != hipSuccess) return e;
-      attr6 = true;
+      attr = true;
     }
-    hipLaunchKernelGGL(gemm_tn6_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
+    hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
                        Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
+#endif
+  static bool attr6 = false;
+  if (!attr6) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn6_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    if (e != hipSuccess) return e;
+    attr6 = true;
+  }
+  hipLaunchKernelGGL(gemm_tn6_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
                      Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
   return hipGetLastError();
 }

@@ -22,7 +22,7 @@
 // by then more than one K-step (≈0.5 µs) separates the wait from the epilogue's last stores.
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {

@@ -22,8 +22,8 @@
 // for A/B runs; the four-wave epilogue is also slower (half as many waves do the same store work).
 #include <stdlib.h>
 
-#include "common.cuh"
-#include "epilogue.cuh"
+#include "common.hip.h"
+#include "epilogue.hip.h"
 #include "kernels.h"
 
 namespace sgl {

@@ -3,8 +3,8 @@
 // It exists for the fp32-strict compute mode (parity against the fp32 CPU oracle through the same host
 // orchestration and the same fused epilogues as the bf16 MFMA path); it is not a performance path.
 // 64x64 tile, BK = 16, 256 threads, 4x4 outputs per thread, fp32 FMA accumulation in k order.
-#include "common.cuh"
-#include "epilogue.cuh"
+#include "common.hip.h"
+#include "epilogue.hip.h"
 #include "kernels.h"
 
 namespace sgl {

@@ -3,7 +3,7 @@
 // HBM-bound: one wave (64 lanes) per row, the row lives in registers (float4 per lane), fp32 statistics by
 // wave-64 shuffles, output written in the GEMM operand dtype (bf16 or fp32).
 // Algorithmic bytes per row: fwd  D*4 (x) + D*sizeof(T) (y);  bwd  D*(4 + sizeof(T) + 4 [+4 dres] + sizeof(T)).
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 
 namespace sgl {

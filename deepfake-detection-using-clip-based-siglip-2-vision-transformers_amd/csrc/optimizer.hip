@@ -25,7 +25,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "siglip_hip.h"
 
 namespace sgl {

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "common.cuh"
+#include "common.hip.h"
 #include "kernels.h"
 #include "siglip_hip.h"
 

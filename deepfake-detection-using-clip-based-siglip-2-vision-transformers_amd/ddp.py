@@ -19,8 +19,17 @@ collective is the sum of parameter gradients.
 * **1/world.**  ``average=True`` scales all chunks with ONE ``torch._foreach_mul_`` in ``finish()``;
   ``average="defer"`` leaves sums in ``.grad`` and the consumer applies the factor: ``FusedAdamW(grad_scale=1/world)``
   folds it into the clip coefficient it already multiplies every gradient by (no extra pass over the gradients).
-* ``no_sync()`` suppresses the exchange for gradient-accumulation micro-steps; ``reduce_grads`` (everything outside the
-  encoder: decoder, heads) is asynchronous and completed by ``finish()`` as well.
+* ``no_sync()`` suppresses the exchange for gradient-accumulation micro-steps (the reference accumulates:
+  Siglip2sidafrozen.py:1390 ``loss / current_grad_accum``).  The micro-step that leaves the context must exchange the
+  ACCUMULATED gradient, not just its own contribution: when a trainable encoder parameter already carries a ``.grad`` the
+  in-backward hand-off is skipped and ``reduce_accumulated`` runs from an autograd-engine callback after every
+  ``AccumulateGrad`` of the pass has fired, one collective per chunk over the memory ``.grad`` lives in.
+* ``reduce_grads`` (everything outside the encoder: decoder, heads) is asynchronous and completed by ``finish()`` as well.
+* Chunk sizes taper (``SiglipVisionModelHIP._bucket_layout``): the chunk that completes last holds one block (+ the
+  embeddings), so the exchange that cannot overlap anything is 67 MB, not 244 MB.
+* ``all_gather_eval`` collects per-rank logits / labels for epoch metrics (Siglip2sidafrozen.py:1424-1548).
+* RCCL's channel kernels take CUs from GEMMs that occupy every CU; ``NCCL_MAX_NCHANNELS`` (read by RCCL at
+  ``init_process_group``; ``bench.py --rccl-channels``) bounds how many.
 
 Nothing here has been timed on more than one GPU by the builder (the 8-GPU node is the driver's): correctness is covered by
 world-2 gloo tests, the scaling curve is whatever the driver's SCALE run measures.
@@ -49,6 +58,8 @@ class GradBucketReducer:
         self._pending: list = []          # (kind, flat, work, extra)
         self._heads: list = []            # (flat, params) of reduce_grads calls in flight
         self.collectives_issued = 0       # statistics for tests / bench
+        self.time_exposed = False         # bench: HIP events around finish()'s waits = communication nothing overlapped
+        self._exposed: list = []
 
     # ---- wiring ------------------------------------------------------------------------------------------
     def attach(self, encoder_module) -> "GradBucketReducer":
@@ -69,13 +80,24 @@ class GradBucketReducer:
 
     @contextlib.contextmanager
     def no_sync(self):
-        """Gradient-accumulation micro-steps: backward runs without any collective; the step that leaves the context
-        exchanges the accumulated ``.grad`` through ``reduce_grads`` / its own backward."""
+        """Gradient-accumulation micro-steps: backward runs without any collective; the first backward after the context
+        exchanges the ACCUMULATED ``.grad`` (``reduce_accumulated``, called by the encoder's autograd formula), and
+        ``reduce_grads`` does the same for everything outside the encoder."""
         prev, self._sync = self._sync, False
         try:
             yield self
         finally:
             self._sync = prev
+
+    def syncing(self) -> bool:
+        """Will a chunk handed to ``reduce_bucket`` really be exchanged?"""
+        return self._sync and self.world_size() > 1
+
+    def exposed_ms(self) -> list:
+        """Milliseconds the launch stream spent blocked in each ``finish()`` since the last call (``time_exposed``)."""
+        out = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed.clear()
+        return out
 
     # ---- called from the encoder's backward -----------------------------------------------------------------
     def reduce_bucket(self, flat: torch.Tensor) -> None:
@@ -103,6 +125,10 @@ class GradBucketReducer:
         if not self._pending and not self._heads:
             return
         world = self.world_size()
+        ev = None
+        if self.time_exposed and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         done: list[torch.Tensor] = []
         gathers = []
         for kind, flat, work, extra in self._pending:
@@ -122,6 +148,9 @@ class GradBucketReducer:
         for flat, params, work in self._heads:
             work.wait()
             done.append(flat)
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         if self.average is True and done:
             torch._foreach_mul_(done, 1.0 / world)
         for flat, params, _ in self._heads:
@@ -131,6 +160,26 @@ class GradBucketReducer:
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
         self._heads.clear()
+
+    # ---- gradient accumulation: the micro-step after no_sync() exchanges what .grad holds ---------------------
+    def reduce_accumulated(self, chunks) -> None:
+        """``chunks`` = [(total_elems, [(param, offset, numel)])] in the encoder's chunk layout.  Called once autograd has
+        accumulated this pass into ``.grad``.  When a chunk's gradients still sit at their offsets inside one allocation
+        (the flat tensor an earlier micro-step's backward wrote: ``AccumulateGrad`` adopts the views and later adds in
+        place) that memory is exchanged directly, one collective per chunk as in the overlapped case; otherwise the chunk
+        goes through a packed copy.  Completed (and averaged) by the ``finish()`` at the end."""
+        if not self.syncing():
+            return
+        for total, entries in chunks:
+            entries = [(p, off, n) for p, off, n in entries if p.grad is not None]
+            if not entries:
+                continue
+            flat = _common_flat(entries, total)
+            if flat is not None:
+                self.reduce_bucket(flat)
+            else:
+                self.reduce_grads([p for p, _, _ in entries], async_op=True)
+        self.finish()
 
     # ---- everything outside the encoder (heads, decoder): one bucket after backward ---------------------------
     def reduce_grads(self, params: Iterable[torch.nn.Parameter], async_op: bool = False) -> None:
@@ -145,6 +194,49 @@ class GradBucketReducer:
         self._heads.append((flat, ps, work))
         if not async_op:
             self.finish()
+
+
+def _common_flat(entries, total) -> Optional[torch.Tensor]:
+    """The fp32 tensor of ``total`` elements whose [off, off+n) ranges ARE the ``.grad`` of ``entries``' parameters, or
+    None when the gradients do not sit in one allocation at those offsets."""
+    p0, off0, _ = entries[0]
+    g0 = p0.grad
+    if g0.dtype != torch.float32:
+        return None
+    st = g0.untyped_storage()
+    start = g0.data_ptr() - 4 * off0
+    if start < st.data_ptr() or start + 4 * total > st.data_ptr() + st.nbytes():
+        return None
+    for p, off, n in entries:
+        g = p.grad
+        if (g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != n or g.data_ptr() != start + 4 * off
+                or g.untyped_storage().data_ptr() != st.data_ptr()):
+            return None
+    return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, (start - st.data_ptr()) // 4, (total,))
+
+
+def all_gather_eval(*tensors: torch.Tensor, group=None):
+    """Validation-loop collective (the reference's validate() computes epoch metrics over every sample,
+    Siglip2sidafrozen.py:1424-1548): concatenate each rank's per-sample tensors (logits, labels, ...) along dim 0, in rank
+    order, on every rank.  Ranks may hold different numbers of samples (the last shard of ``shard_batch``); trailing
+    dimensions must agree.  Returns one tensor per argument (a single tensor for a single argument)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors[0] if len(tensors) == 1 else tuple(tensors)
+    world = dist.get_world_size(group)
+    outs = []
+    dev = tensors[0].device
+    counts = torch.tensor([t.shape[0] for t in tensors], dtype=torch.int64, device=dev)
+    all_counts = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    for ti, t in enumerate(tensors):
+        ns = [int(c[ti]) for c in all_counts]
+        cap = max(ns)
+        pad = t.new_zeros((cap, *t.shape[1:]))
+        pad[:t.shape[0]] = t
+        got = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(got, pad.contiguous(), group=group)
+        outs.append(torch.cat([g[:n] for g, n in zip(got, ns)], dim=0))
+    return outs[0] if len(outs) == 1 else tuple(outs)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

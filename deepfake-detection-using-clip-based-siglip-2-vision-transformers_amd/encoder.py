@@ -148,6 +148,25 @@ def _geometry(mod, pixel_values, layout=0, img_h=0, img_w=0):
     return B, H, W, gh * gw, B * gh * gw, (gh, gw)
 
 
+def _taper(order, max_chunks):
+    """Cut the completion-ordered group list into at most ``max_chunks`` runs whose lengths shrink towards the END: the
+    exchange of the last chunk overlaps nothing (backward is over when it starts), the first has the whole backward to
+    hide behind.  Boundaries, counted from the end, follow j(j+1)/2 (28 groups, 8 chunks -> 6,6,4,4,3,3,1,1); the small
+    embeddings group rides with the block it follows."""
+    tail = [order[-1]] if len(order) > 1 and order[-1] == "emb" else []
+    body = order[:len(order) - len(tail)]
+    n, c = len(body), max(1, min(max_chunks, len(body)))
+    tri = c * (c + 1) // 2
+    cuts = sorted({n - min(n, max(j, round(n * j * (j + 1) / 2 / tri))) for j in range(1, c)} | {0, n})
+    runs = [body[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    if tail:
+        if runs:
+            runs[-1] = runs[-1] + tail
+        else:
+            runs = [tail]
+    return runs
+
+
 @torch.library.custom_op("siglip_hip::encoder_fwd", mutates_args=())
 def encoder_fwd(pixel_values: torch.Tensor, params: Sequence[torch.Tensor], handle: int, train: bool, interp: bool,
                 want_pooled: bool, tap_ids: Sequence[int], first_trainable: int, layout: int, img_h: int,
@@ -283,10 +302,13 @@ def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Te
             for i in groups["head"]:
                 grads_out[i].zero_()
         reducer = mod._grad_reducer
+        # gradient accumulation (micro-steps under reducer.no_sync() came before): what must be exchanged is the SUM in
+        # .grad, which autograd forms after this op returns, so nothing is handed over from here (see _encoder_backward)
+        overlapped = reducer is not None and not mod._accumulating(needs)
 
         def group_done(grp):
             """Hand a chunk to the reducer once its last group (in completion order) is complete."""
-            if reducer is not None and grp in chunk_of and last_of[chunk_of[grp]] == grp:
+            if overlapped and grp in chunk_of and last_of[chunk_of[grp]] == grp:
                 reducer.reduce_bucket(flats[chunk_of[grp]])
 
         gl = (_lib.SglLayerPtrs * max(L, 1))()
@@ -325,7 +347,7 @@ def encoder_bwd(grads: Sequence[Optional[torch.Tensor]], taps: Sequence[torch.Te
                                         saved.data_ptr(), sizes[1], ws.data_ptr(), sizes[2], stream)
             _lib.check(st, "sgl_backward_embed", mod._ctx)
             group_done("emb")
-        if reducer is not None:
+        if overlapped:
             reducer.finish()
     return flats
 
@@ -361,6 +383,14 @@ def _encoder_backward(ctx, grads):
     taps, saved, hs_rest, params = list(saved_t[:nt]), saved_t[nt], saved_t[nt + 1], list(saved_t[nt + 2:])
     needs = [bool(n) for n in ctx.needs_input_grad[1]] if isinstance(ctx.needs_input_grad[1], (list, tuple)) \
         else [p.requires_grad for p in params]
+    mod = _module_of(ctx.handle)
+    if mod._grad_reducer is not None and mod._grad_reducer.syncing() and mod._accumulating(needs):
+        # the exchange of the accumulated gradients runs when the whole autograd pass (every AccumulateGrad) is over
+        layout, _ = mod._bucket_layout(needs)
+        plist = mod._flat_params()
+        work = [(total, [(plist[i], off, n) for i, off, n in entries]) for total, _, entries in layout]
+        reducer = mod._grad_reducer
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: reducer.reduce_accumulated(work))
     flats = torch.ops.siglip_hip.encoder_bwd(list(grads[:2 + nt]), taps, saved, hs_rest, params, ctx.handle, ctx.image_hw,
                                              ctx.interp, ctx.want_pooled, ctx.tap_ids, needs)
     chunks, _ = _module_of(ctx.handle)._bucket_layout(needs)
@@ -616,12 +646,10 @@ class SiglipVisionModelHIP(nn.Module):
         L = self.config.num_hidden_layers
         order = [g_ for g_ in (["head"] + [f"layer{l}" for l in range(L - 1, -1, -1)] + ["emb"]) if g_ in groups]
         max_buckets = getattr(self._grad_reducer, "max_buckets", 8) if self._grad_reducer is not None else 8
-        per = max(1, -(-len(order) // max(1, max_buckets)))
         # q/k/v weight (and bias) gradients back to back: the C side then runs them as one dW GEMM / one column sum
         rank = {"q_w": 0, "k_w": 1, "v_w": 2, "q_b": 3, "k_b": 4, "v_b": 5}
         chunks = []
-        for c0 in range(0, len(order), per):
-            members = order[c0:c0 + per]
+        for members in _taper(order, max(1, max_buckets)):
             off, entries = 0, []
             for grp in members:
                 idxs = sorted(groups[grp], key=lambda i: (rank.get(names[i][1], 6), i))
@@ -631,6 +659,10 @@ class SiglipVisionModelHIP(nn.Module):
                     off += (n + 3) // 4 * 4
             chunks.append((off, members, entries))
         return chunks, groups
+
+    def _accumulating(self, needs) -> bool:
+        """Does a parameter this backward differentiates already carry a gradient (accumulation micro-steps)?"""
+        return any(n and p.grad is not None for n, p in zip(needs, self._flat_params()))
 
     def _alloc_buckets(self, chunks, dev):
         """The flat tensors of ``_bucket_layout``.  The C side overwrites every element, so they are reused from step to

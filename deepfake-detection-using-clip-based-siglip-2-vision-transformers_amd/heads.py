@@ -424,11 +424,15 @@ class SigLIP2MTL(nn.Module):
         seg_logits = self.decoder(feats, (g, g), target_size=int(pixel_values.shape[-1]), return_lowres=return_lowres)
         return cls_logit, seg_logits
 
-    def training_loss(self, pixel_values, y_class, masks, has_mask, lam_seg: float = 1.0):
+    def training_loss(self, pixel_values, y_class, masks, has_mask, lam_seg: float = 1.0, bce_w: float = 1.0,
+                      dice_w: float = 0.5):
         """The SID train-step loss (Siglip2sidafrozen.py:1375-1389: CE + lam * BCE/Dice on the samples with a mask) with the
-        decoder tail fused for HBM: low-res logits -> loss directly.  Returns (loss, cls_logit, seg_logits_lowres)."""
+        decoder tail fused for HBM: low-res logits -> loss directly.  ``bce_w`` / ``dice_w`` are the epoch-scheduled
+        ``current_bce_w`` / ``current_dice_w`` the reference passes to ``bce_dice_loss`` (Siglip2sidafrozen.py:1340-1351,
+        1389).  Returns (loss, cls_logit, seg_logits_lowres)."""
         cls_logit, seg_lr = self.forward(pixel_values, return_lowres=True)
-        loss = F.cross_entropy(cls_logit.float(), y_class) + lam_seg * bce_dice_loss_from_lowres(seg_lr, masks, has_mask)
+        loss = F.cross_entropy(cls_logit.float(), y_class) + lam_seg * bce_dice_loss_from_lowres(
+            seg_lr, masks, has_mask, bce_w=bce_w, dice_w=dice_w)
         return loss, cls_logit, seg_lr
 
 

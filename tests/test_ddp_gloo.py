@@ -76,7 +76,34 @@ def _worker(rank, world, port, q):
             want = torch.stack([a.bfloat16().float() for a in allb]).sum(0)      # SUM (average deferred), bf16 inputs
             ok_wire = ok_wire and torch.allclose(b, want.bfloat16().float(), atol=1e-6)
         ok_wire = ok_wire and torch.allclose(lin2.weight.grad, torch.full_like(lin2.weight, 3.0))
-        q.put((rank, ok_buckets, ok_head and ok_nosync and ok_wire, ok_bcast, pkg.ddp.shard_batch(11, rank, world)))
+        # gradient accumulation: .grad views inside one flat (what AccumulateGrad adopts from the encoder's backward) are
+        # exchanged in place, one collective; scattered .grad tensors go through the packed path; both end as the mean
+        red3 = pkg.GradBucketReducer()
+        flat = torch.arange(40, dtype=torch.float32) * (rank + 1)
+        pa, pb, pc = (torch.nn.Parameter(torch.zeros(n)) for n in (10, 7, 20))
+        pa.grad, pb.grad, pc.grad = flat[0:10], flat[12:19], flat[20:40]
+        ps = torch.nn.Parameter(torch.zeros(5))
+        ps.grad = torch.full((5,), float(rank + 1))
+        before = red3.collectives_issued
+        red3.reduce_accumulated([(40, [(pa, 0, 10), (pb, 12, 7), (pc, 20, 20)]), (8, [(ps, 0, 5)])])
+        ok_acc = red3.collectives_issued - before == 2 and pa.grad.data_ptr() == flat.data_ptr()
+        ok_acc = ok_acc and torch.allclose(pb.grad, torch.arange(12, 19, dtype=torch.float32) * 1.5)
+        ok_acc = ok_acc and torch.allclose(pc.grad, torch.arange(20, 40, dtype=torch.float32) * 1.5)
+        ok_acc = ok_acc and torch.allclose(ps.grad, torch.full((5,), 1.5))
+        pd = torch.nn.Parameter(torch.zeros(4))
+        pd.grad = torch.full((4,), float(rank))          # a gradient that is NOT at its offset in pa's allocation
+        red3.reduce_accumulated([(16, [(pa, 0, 10), (pd, 12, 4)])])
+        ok_acc = ok_acc and torch.allclose(pd.grad, torch.full((4,), 0.5)) and \
+            torch.allclose(pa.grad, torch.arange(10, dtype=torch.float32) * 1.5)   # already equal on both ranks
+        # eval-side all-gather of per-sample logits / labels, uneven shards
+        n_mine = 3 + rank
+        lg = torch.arange(n_mine * 2, dtype=torch.float32).view(n_mine, 2) + 100 * rank
+        lb = torch.arange(n_mine) + 10 * rank
+        all_lg, all_lb = pkg.ddp.all_gather_eval(lg, lb)
+        ok_gather = all_lg.shape == (7, 2) and all_lb.tolist() == [0, 1, 2, 10, 11, 12, 13] and \
+            torch.equal(all_lg[3:], torch.arange(8, dtype=torch.float32).view(4, 2) + 100)
+        q.put((rank, ok_buckets, ok_head and ok_nosync and ok_wire and ok_acc and ok_gather, ok_bcast,
+               pkg.ddp.shard_batch(11, rank, world)))
     finally:
         dist.destroy_process_group()
 
@@ -268,3 +295,83 @@ def test_sid_frozen_prefix_two_ranks_identical_parameters_after_two_steps():
         assert worst < 5e-5, f"rank {rank}: {who} differs from the single-process run by {worst}"
         # per step: 2 encoder chunks (max_buckets=2: head+block 1) + 1 flat message for decoder/cls head
         assert n_coll == 2 * 3, n_coll
+
+
+def _accum_worker(rank, world, port, q):
+    """Gradient accumulation across ranks: micro-step 1 under no_sync(), micro-step 2 syncing.  Every
+    rank must end with the SAME gradients, equal to one single-process pass over all four micro-batches."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = pkg.get_config("hostile")
+        model = pkg.SiglipVisionModelHIP(cfg, compute_dtype="fp32")
+        model.load_state_dict(pkg.weights.seeded_state_dict(cfg, 4))
+        model = model.to("cuda")
+        head = torch.nn.Linear(cfg.hidden_size, 1).cuda()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            head.weight.copy_(pkg.weights.seeded_tensor("acc_head", tuple(head.weight.shape), 0.1).cuda())
+            head.bias.zero_()
+        red = pkg.GradBucketReducer(max_buckets=2).attach(model)
+        xs = [[pkg.weights.seeded_pixels(2, 42, 42, seed=90 + 10 * r + m).cuda() for m in range(2)] for r in range(world)]
+
+        def loss_of(x):
+            out = model(pixel_values=x, output_hidden_states=True, interpolate_pos_encoding=True)
+            return (head(out.pooler_output).square().sum() + out.hidden_states[1].mean()) / 2      # / accumulation steps
+
+        for step in range(2):                                       # two optimizer steps' worth, to reuse cached buckets
+            for p in list(model.parameters()) + list(head.parameters()):
+                p.grad = None
+            with red.no_sync():
+                loss_of(xs[rank][0]).backward()
+                red.reduce_grads(head.parameters())                 # no-op under no_sync
+            issued = red.collectives_issued
+            loss_of(xs[rank][1]).backward()
+            red.reduce_grads(head.parameters())
+            n_coll = red.collectives_issued - issued
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().cpu().clone() for n, p in list(model.named_parameters()) + list(head.named_parameters())}
+        flat = torch.cat([v.reshape(-1) for v in got.values()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        model._grad_reducer = None
+        for p in list(model.parameters()) + list(head.parameters()):
+            p.grad = None
+        total = 0
+        for r in range(world):
+            for m in range(2):
+                total = total + loss_of(xs[r][m]) / world
+        total.backward()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for n, p in list(model.named_parameters()) + list(head.named_parameters()):
+            ref = p.grad.detach().cpu()
+            worst = max(worst, ((got[n] - ref).abs().max() / (ref.abs().max() + 1e-12)).item())
+        q.put((rank, worst, bool(torch.equal(both[0], both[1])), n_coll))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_with_no_sync_exchanges_the_accumulated_sum():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, worst, same, n_coll in res:
+        assert same, "ranks hold different gradients after the syncing micro-step"
+        assert worst < 2e-5, f"rank {rank}: accumulated + averaged gradients differ from the joined batch by {worst}"
+        assert n_coll == 3, n_coll         # 2 encoder chunks (in place, from the engine callback) + the head message
