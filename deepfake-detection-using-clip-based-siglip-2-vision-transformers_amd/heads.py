@@ -570,6 +570,20 @@ class SEBinaryHead(nn.Module):
         return self.classifier(f * self.se(f)).squeeze(-1)
 
 
+class ImageBinaryHead(nn.Module):
+    """Head of the HiDF image-track classifier (``BinaryClassifier.classifier`` + the L2-norm in front of it,
+    simple_classifier.py:141-148,159-164): f/||f|| -> LayerNorm -> Dropout(0.3) -> Linear(D, D/2) -> GELU -> Dropout(0.2) ->
+    Linear(D/2, 1) -> (B,).  Parameter names equal the reference's (``classifier.0.weight`` ...)."""
+
+    def __init__(self, dim: int = 1024):
+        super().__init__()
+        self.classifier = nn.Sequential(nn.LayerNorm(dim), nn.Dropout(0.3), nn.Linear(dim, dim // 2), nn.GELU(),
+                                        nn.Dropout(0.2), nn.Linear(dim // 2, 1))
+
+    def forward(self, pooled):
+        return self.classifier(l2_normalize(pooled)).squeeze(-1)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # fusion / calibration  (train_fusion_head_only.py:230-317, appv3.py:1497-1510,1573-1578,3147-3182, coral.py:300-322)
 # ---------------------------------------------------------------------------------------------------------
@@ -928,6 +942,41 @@ class BinaryVideoClassifierHIP(_FlatHeadKeys):
     def forward(self, x):
         b, t, c, h, w = x.shape
         return self.head(self.vision_encoder.encode_image(x.view(b * t, c, h, w)), batch_size=b)
+
+
+class ImageBinaryClassifierHIP(_FlatHeadKeys):
+    """`BinaryClassifier` of the HiDF image track (simple_classifier.py:115-164; BASELINE config 3 = this head on
+    so400m-patch14-384): bilinear resize to the model resolution if needed -> `backbone.encode_image` -> L2-norm -> head
+    -> (B,) logits.  ``partially_unfreeze_backbone()`` is the script's default fine-tuning recipe (:483-496)."""
+
+    def __init__(self, backbone: nn.Module):
+        super().__init__()
+        self.backbone = backbone
+        self.resolution = backbone.image_size
+        self.feature_dim = backbone.embed_dim
+        self.head = ImageBinaryHead(self.feature_dim)
+
+    def forward(self, x):
+        if x.shape[-1] != self.resolution:
+            x = F.interpolate(x, size=(self.resolution, self.resolution), mode="bilinear")
+        return self.head(self.backbone.encode_image(x))
+
+    def partially_unfreeze_backbone(self, last_blocks: int = 2) -> int:
+        """simple_classifier.py:483-496: freeze the whole backbone, then re-enable every parameter whose open_clip/timm
+        NAME contains one of ``blocks.<L-1>`` ... ``blocks.<L-last_blocks>``, ``ln_final``, ``norm`` (the script
+        hard-codes ``blocks.23`` / ``blocks.22`` for its 24-block tower).  Substring matching is kept as is: ``norm`` also
+        selects ``norm1`` / ``norm2`` of EVERY block, the final norm and the pooling head's norm, and ``blocks.2`` style
+        prefixes behave as in the script.  Returns the number of re-enabled parameters (what the script prints)."""
+        for prm in self.backbone.parameters():
+            prm.requires_grad = False
+        depth = self.backbone.visual.config.num_hidden_layers
+        keys = [f"blocks.{depth - 1 - i}" for i in range(last_blocks)] + ["ln_final", "norm"]
+        n = 0
+        for name, prm in self.backbone.named_parameters():
+            if any(k in name for k in keys):
+                prm.requires_grad = True
+                n += prm.numel()
+        return n
 
 
 class SEBinaryClassifierHIP(_FlatHeadKeys):

@@ -170,6 +170,17 @@ def main():
     vid.vision_encoder.feat = vfeat
     rec["video.logits"] = vid(torch.zeros(3, 4, 3, 8, 8)).detach().numpy()
 
+    # ---- HiDF image-track head (simple_classifier.py:115-164; BASELINE config 3) -----------------------------------
+    for size, dim in (("small", 768), ("large", 1024)):
+        holder["dim"] = dim
+        ns = base_ns()
+        ns.update(open_clip=fake_open_clip(holder), OPENCLIP_AVAILABLE=True, print=lambda *a, **k: None)
+        lift(os.path.join(REF, "simple_classifier.py"), ["BinaryClassifier"], ns)
+        img = ns["BinaryClassifier"](model_size=size, device="cpu").eval()
+        seed_module(img, f"image.{size}.")
+        img.backbone.feat = T(f"image_features_{size}", (5, dim), 2.0)
+        rec[f"image.{size}.logits"] = img(torch.zeros(5, 3, img.resolution, img.resolution)).detach().numpy()
+
     # ---- SE head, FreqMLP v5, adaptive fusion (train_fusion_head_only.py) ------------------------------------------
     holder["dim"] = 1024
     ns = base_ns()

@@ -100,6 +100,16 @@ def test_video_and_se_heads_match_reference(pkg, dev):
     close(se.to(dev)(T(pkg, "se_features", (3, dim), 2.0).to(dev)), REC["se.logits"])
 
 
+@pytest.mark.parametrize("size,dim", [("small", 768), ("large", 1024)])
+def test_image_binary_head_matches_reference(pkg, size, dim, dev):
+    """HiDF image-track head (simple_classifier.py:141-148,159-164; BASELINE config 3) against the reference class."""
+    head = pkg.heads.ImageBinaryHead(dim).eval()
+    seed_module(pkg, head, f"image.{size}.")
+    assert [n for n, _ in head.named_parameters()] == ["classifier.0.weight", "classifier.0.bias", "classifier.2.weight",
+                                                       "classifier.2.bias", "classifier.5.weight", "classifier.5.bias"]
+    close(head.to(dev)(T(pkg, f"image_features_{size}", (5, dim), 2.0).to(dev)), REC[f"image.{size}.logits"])
+
+
 def test_fusion_and_freq_match_reference(pkg, dev):
     H = pkg.heads
     fm = H.FreqMLPv5().eval()
