@@ -225,7 +225,7 @@ def step_breakdown(pkg, cfg, batch, res, reps, nt_per_shape):
                                                      N2, 0, scratch.data_ptr(), scratch.numel(), st.cuda_stream))
         del A, Bm, out
     fam["tn_dw"] = t_dw
-    qkv = torch.zeros(3, batch, Hh, Ntok, DP, device=dev, dtype=torch.bfloat16)
+    qkv = torch.zeros(3, batch, Hh, Ntok, DP, device=dev, dtype=torch.bfloat16)   # head-major, as EPI_QKV writes it
     qkv[..., :dh] = torch.randn(3, batch, Hh, Ntok, dh, device=dev).bfloat16()
     o = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
     do = torch.randn(M, D, device=dev).bfloat16()
@@ -234,10 +234,11 @@ def step_breakdown(pkg, cfg, batch, res, reps, nt_per_shape):
     dqkv = torch.empty(M, 3 * D, device=dev, dtype=torch.bfloat16)
     fam["attn_fwd"] = timeit(lambda: lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(),
                                                          o.data_ptr(), lse.data_ptr(), batch, Hh, Ntok, dh, DP,
-                                                         st.cuda_stream))
+                                                         0, st.cuda_stream))
     fam["attn_bwd"] = timeit(lambda: lib.sgl_op_attn_bwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(),
                                                          o.data_ptr(), do.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                                         delta.data_ptr(), batch, Hh, Ntok, dh, DP, st.cuda_stream))
+                                                         delta.data_ptr(), batch, Hh, Ntok, dh, DP, 0,
+                                                         st.cuda_stream))
     del qkv, o, do, dqkv
     x = torch.randn(M, D, device=dev)
     gam, bet = torch.randn(D, device=dev), torch.randn(D, device=dev)

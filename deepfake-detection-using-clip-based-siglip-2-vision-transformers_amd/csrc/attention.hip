@@ -2,8 +2,13 @@
 // (SiglipAttention, TF:models/siglip/modeling_siglip.py:273-306; softmax in fp32 as in :241).
 // v_mfma_f32_32x32x16_bf16 throughout, 64-lane wavefronts, 4 waves per workgroup, each wave owns 32 rows.
 //
-// Layouts: q,k,v head-major [B][H][N][DP] (DP = head_dim rounded up to 16; pad columns are zero), written by
-// the QKV GEMM epilogue; out / dout token-major [B*N][H*dh]; dqkv token-major [B*N][3*H*dh].
+// Layouts: q,k,v head-major [B][H][N][DP] (ld = 0; DP = head_dim rounded up to 16, pad columns zero in memory; what the
+// QKV GEMM's EPI_QKV epilogue writes and what the encoder uses), or (ld > 0) straight out of a token-major projection
+// output [B*N][ld]: head h of token row r is the 2*dh-byte segment at r*ld + h*dh (144 B = nine 16-byte chunks for
+// dh = 72), gathered chunk by chunk by the LDS-DMA; the chunks that pad dh up to DP never exist in HBM — their DMA lanes
+// point out of range and the hardware writes zeros into the LDS image.  Measured (round 3, B = 128): the gather costs the
+// three kernels 5-6 % (14 cache lines per DMA instruction instead of 8), more than the plain-store QKV epilogue saves.
+// out / dout token-major [B*N][H*dh]; dqkv token-major [B*N][3*H*dh].
 //
 // Forward ("query on the lane"): Sᵀ = K·Qᵀ so each lane owns one query column and 16 of a 32-key block's scores;
 // the row max / row sum are lane-local plus one cross-half shuffle, the running rescale factor is a per-lane
@@ -23,9 +28,9 @@
 
 namespace sgl {
 
-hipError_t attn_ref_fwd(const float*, const float*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
+hipError_t attn_ref_fwd(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
 hipError_t attn_ref_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                        float*, int, int, int, int, int, hipStream_t);
+                        float*, int, int, int, int, int, int, hipStream_t);
 
 template <int DP>
 struct AttnCfg {
@@ -76,6 +81,27 @@ __device__ __forceinline__ bool head_block(int nb, int BH, int& bh, int& xb) {
 }
 static inline dim3 head_grid(int nb, int BH) { return dim3((unsigned)(8 * ((BH + 7) / 8) * nb)); }
 
+// Where head `hd` of batch `b` lives in a q/k/v source: byte stride between token rows, data chunks per row, buffer extent.
+struct HeadSrc {
+  uint32_t rowbytes, nc, bytes;
+  size_t base;   // element offset of (token 0, column 0) of this head
+};
+__device__ __forceinline__ HeadSrc head_src(int ld, int b, int hd, int H, int N, int dh, int DP) {
+  HeadSrc r;
+  if (ld > 0) {
+    r.rowbytes = (uint32_t)ld * 2u;
+    r.nc = (uint32_t)dh / 8u;
+    r.bytes = (uint32_t)(((size_t)(N - 1) * ld + dh) * 2);
+    r.base = (size_t)b * N * ld + (size_t)hd * dh;
+  } else {
+    r.rowbytes = (uint32_t)DP * 2u;
+    r.nc = (uint32_t)DP / 8u;
+    r.bytes = (uint32_t)((size_t)N * DP * 2);
+    r.base = ((size_t)b * H + hd) * (size_t)N * DP;
+  }
+  return r;
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // ======================================================================================================
@@ -121,8 +147,8 @@ __device__ __forceinline__ uint32_t att_chunk_off(int cidx, int rows, int SC, in
 template <int DP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ out,
-                                                          float* __restrict__ lse, int B, int H, int N, int dh, float c,
-                                                          float scale) {
+                                                          float* __restrict__ lse, int B, int H, int N, int dh, int ld,
+                                                          float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 64;
   constexpr int KBYTES = KT * C::RSTR, VBYTES = KT * C::TSTR, STAGE = KBYTES + VBYTES;
@@ -137,18 +163,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
   const int b = bh / H, hd = bh - b * H;
   const int q0 = xb * 128 + w * 32;
-  const size_t mat = (size_t)bh * N * DP;
-  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
-  const u32x4 dk_ = att_desc(K + mat, mbytes);
-  const u32x4 dv_ = att_desc(V + mat, mbytes);
+  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + src.base, src.bytes);
+  const u32x4 dk_ = att_desc(K + src.base, src.bytes);
+  const u32x4 dv_ = att_desc(V + src.base, src.bytes);
   const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
 
   const int qi = lane & 31, hh = lane >> 5;
   bf16x8 qf[C::KS];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks)
-    qf[ks] = as_bf16x8(a_ldg(rq, (q0 + qi < N) ? (uint32_t)(((q0 + qi) * DP + 16 * ks + 8 * hh) * 2) : SGL_OOB));
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const uint32_t ch = (uint32_t)(2 * ks + hh);
+    qf[ks] = as_bf16x8(a_ldg(rq, (q0 + qi < N && ch < src.nc) ? (uint32_t)(q0 + qi) * src.rowbytes + ch * 16u : SGL_OOB));
+  }
 
   // K/V tiles: global -> LDS by DMA (see the dK/dV kernel), two stages (three workgroups per CU leave no room for a third):
   // tile+1 is requested right after the barrier that frees its stage and has the whole tile to land.  Slots sl = w + 4j;
@@ -157,16 +184,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int sl = w + 4 * j;
-    voff[j] = (sl < NIK) ? att_chunk_off(sl * 64 + lane, KT, SCK, DP / 8, (uint32_t)DP * 2u)
-                         : att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, DP / 8, (uint32_t)DP * 2u);
+    voff[j] = (sl < NIK) ? att_chunk_off(sl * 64 + lane, KT, SCK, (int)src.nc, src.rowbytes)
+                         : att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, (int)src.nc, src.rowbytes);
   }
+  const uint32_t tile_adv = (uint32_t)KT * src.rowbytes;
   auto issue = [&](int stage) {
     const uint32_t sb = lds0 + (uint32_t)(stage * STAGE);
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       const int sl = w + 4 * j;
       if (sl < NSLOT) att_dma16(sl < NIK ? dk_ : dv_, sb + (uint32_t)sl * 1024u, voff[j]);
-      voff[j] += (uint32_t)(KT * DP * 2);
+      voff[j] += tile_adv;
     }
   };
 
@@ -270,7 +298,7 @@ template <int DP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                              const bf16* __restrict__ V, const bf16* __restrict__ dO,
                                                              const float* __restrict__ aux, bf16* __restrict__ dqkv,
-                                                             int B, int H, int N, int dh, float c, float scale) {
+                                                             int B, int H, int N, int dh, int ld, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int QT = 32;
   constexpr int SC = C::DSTR / 16;                         // chunks per image row (13)
@@ -287,12 +315,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
   const int key0 = xb * 128 + w * 32;
-  const size_t mat = (size_t)bh * N * DP;
-  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
-  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + mat, mbytes);
-  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + mat, mbytes);
+  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + src.base, src.bytes);
+  const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + src.base, src.bytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
-  const u32x4 dq_ = att_desc(Q + mat, mbytes);
+  const u32x4 dq_ = att_desc(Q + src.base, src.bytes);
   const u32x4 ddo = att_desc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
   const u32x4 dax = att_desc(aux + (size_t)bh * N * 2, (uint32_t)((size_t)N * 8));
   const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
@@ -301,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   bf16x8 kfr[C::KS], vfr[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
-    const uint32_t off = (key0 + li < N) ? (uint32_t)(((key0 + li) * DP + 16 * ks + 8 * hh) * 2) : SGL_OOB;
+    const uint32_t ch = (uint32_t)(2 * ks + hh);
+    const uint32_t off = (key0 + li < N && ch < src.nc) ? (uint32_t)(key0 + li) * src.rowbytes + ch * 16u : SGL_OOB;
     kfr[ks] = as_bf16x8(a_ldg(rk, off));
     vfr[ks] = as_bf16x8(a_ldg(rv, off));
   }
@@ -316,8 +344,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   for (int j = 0; j < 4; ++j) {
     const int sl = w + 4 * j;
     if (sl < NIS) {
-      voff[j] = att_chunk_off(sl * 64 + lane, QT, SC, DP / 8, (uint32_t)DP * 2u);
-      vadv[j] = (uint32_t)(QT * DP * 2);
+      voff[j] = att_chunk_off(sl * 64 + lane, QT, SC, (int)src.nc, src.rowbytes);
+      vadv[j] = (uint32_t)QT * src.rowbytes;
     } else if (sl < 2 * NIS) {
       voff[j] = att_chunk_off((sl - NIS) * 64 + lane, QT, SC, dh / 8, (uint32_t)D * 2u);
       vadv[j] = (uint32_t)(QT * D * 2);
@@ -477,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
                                                             const bf16* __restrict__ V, const bf16* __restrict__ O,
                                                             const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                             float* __restrict__ aux, bf16* __restrict__ dqkv,
-                                                            int B, int H, int N, int dh, float c, float scale) {
+                                                            int B, int H, int N, int dh, int ld, float c, float scale) {
   using C = AttnCfg<DP>;
   constexpr int KT = 32;
   constexpr int SCK = C::DSTR / 16, SCV = C::RSTR / 16;   // chunks per image row: K (dual-use image), V (row reads only)
@@ -494,13 +522,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
   const int q0 = xb * 128 + w * 32;
-  const size_t mat = (size_t)bh * N * DP;
-  const uint32_t mbytes = (uint32_t)((size_t)N * DP * 2);
-  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + mat, mbytes);
+  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + src.base, src.bytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
-  const u32x4 dk_ = att_desc(K + mat, mbytes);
-  const u32x4 dv_ = att_desc(V + mat, mbytes);
+  const u32x4 dk_ = att_desc(K + src.base, src.bytes);
+  const u32x4 dv_ = att_desc(V + src.base, src.bytes);
   const uint32_t lds0 = (uint32_t)(size_t)((SGL_LDS char*)smem);
 
   const int li = lane & 31, hh = lane >> 5;
@@ -509,7 +536,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
     const int col = 16 * ks + 8 * hh;
-    qf[ks] = as_bf16x8(a_ldg(rq, (q < N) ? (uint32_t)((q * DP + col) * 2) : SGL_OOB));
+    qf[ks] = as_bf16x8(a_ldg(rq, (q < N && (uint32_t)(col >> 3) < src.nc) ? (uint32_t)q * src.rowbytes + (uint32_t)col * 2u
+                                                                           : SGL_OOB));
     dof[ks] = as_bf16x8(a_ldg(rdo, (q < N && col < dh) ? (uint32_t)(((size_t)q * D + col) * 2) : SGL_OOB));
   }
   // delta = rowsum(dO ∘ O) of this lane's query, computed here (each lane holds half of its row of dO; O's half is loaded
@@ -540,18 +568,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   for (int j = 0; j < 4; ++j) {
     const int sl = w + 4 * j;
     if (sl < NIK) {
-      voff[j] = att_chunk_off(sl * 64 + lane, KT, SCK, DP / 8, (uint32_t)DP * 2u);
+      voff[j] = att_chunk_off(sl * 64 + lane, KT, SCK, (int)src.nc, src.rowbytes);
       dsc[j] = dk_;
       ldst[j] = (uint32_t)sl * 1024u;
     } else {
-      voff[j] = att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, DP / 8, (uint32_t)DP * 2u);
+      voff[j] = att_chunk_off((sl - NIK) * 64 + lane, KT, SCV, (int)src.nc, src.rowbytes);
       dsc[j] = dv_;
       ldst[j] = (uint32_t)(KIMG + (sl - NIK) * 1024);
     }
   }
   auto issue1 = [&](int j, int stage) {   // tiles past the end read out of range: zeros into a stage nobody reads again
     if (w + 4 * j < NSLOT) att_dma16(dsc[j], lds0 + (uint32_t)(stage * STAGE) + ldst[j], voff[j]);
-    voff[j] += (uint32_t)(KT * DP * 2);
+    voff[j] += (uint32_t)KT * src.rowbytes;
   };
 
   f32x16 dq[C::DT];
@@ -664,18 +692,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
 // ======================================================================================================
 template <int DP>
 static hipError_t fwd_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, float* lse, int B, int H, int N,
-                             int dh, hipStream_t s) {
+                             int dh, int ld, hipStream_t s) {
   using C = AttnCfg<DP>;
   constexpr int smem = 2 * (64 * C::RSTR + 64 * C::TSTR);
   const float scale = 1.0f / sqrtf((float)dh);
   hipLaunchKernelGGL(attn_fwd_kernel<DP>, head_grid((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse, B, H, N,
-                     dh, scale * 1.4426950408889634f, scale);
+                     dh, ld, scale * 1.4426950408889634f, scale);
   return hipGetLastError();
 }
 
 template <int DP>
 static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const bf16* out, const bf16* dout,
-                             const float* lse, bf16* dqkv, float* delta, int B, int H, int N, int dh, hipStream_t s) {
+                             const float* lse, bf16* dqkv, float* delta, int B, int H, int N, int dh, int ld,
+                             hipStream_t s) {
   using C = AttnCfg<DP>;
   const float scale = 1.0f / sqrtf((float)dh);
   const float c = scale * 1.4426950408889634f;
@@ -683,29 +712,32 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   constexpr int smem_kv = 3 * (2 * ((32 * (C::DSTR / 16) + 63) / 64) * 1024 + 32 * 8);
   constexpr int smem_q = 3 * (((32 * (C::DSTR / 16) + 63) / 64) + ((32 * (C::RSTR / 16) + 63) / 64)) * 1024;
   const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N, dh, c, scale);
+  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N, dh, ld, c,
+                     scale);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, c, scale);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, ld, c, scale);
   return hipGetLastError();
 }
 
-static bool attn_shape_ok(int N, int dh, int DP, int H) {
+static bool attn_shape_ok(int N, int dh, int DP, int H, int ld) {
   if (dh % 8 || DP != ((dh + 15) / 16) * 16) return false;
   if (DP != 16 && DP != 32 && DP != 48 && DP != 64 && DP != 80 && DP != 96) return false;
-  if ((size_t)N * DP * 2 >= (1ull << 31)) return false;
+  if (ld < 0 || (ld > 0 && (ld % 8 || ld < H * dh))) return false;          // 16-byte aligned token rows
+  if ((size_t)N * (ld > 0 ? ld : DP) * 2 >= (1ull << 31)) return false;
   if ((size_t)N * H * dh * 2 >= (1ull << 31)) return false;
   return true;
 }
 
 hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void* out, float* lse, int B, int H, int N,
-                    int dh, int DP, hipStream_t s) {
+                    int dh, int DP, int ld, hipStream_t s) {
   if (B * H == 0 || N == 0) return hipSuccess;
   if (dtype == DT_F32)
-    return attn_ref_fwd((const float*)q, (const float*)k, (const float*)v, (float*)out, lse, B, H, N, dh, DP, s);
-  if (!attn_shape_ok(N, dh, DP, H)) return hipErrorInvalidValue;
+    return attn_ref_fwd((const float*)q, (const float*)k, (const float*)v, (float*)out, lse, B, H, N, dh, DP, ld, s);
+  if (!attn_shape_ok(N, dh, DP, H, ld)) return hipErrorInvalidValue;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return hipErrorInvalidValue;
 #define SGL_F(DPV) \
-  case DPV: return fwd_launch<DPV>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, B, H, N, dh, s);
+  case DPV: return fwd_launch<DPV>((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, B, H, N, dh, ld, s);
   switch (DP) {
     SGL_F(16) SGL_F(32) SGL_F(48) SGL_F(64) SGL_F(80) SGL_F(96)
   }
@@ -715,16 +747,17 @@ hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void
 
 hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                     int dtype, void* dqkv, float* delta, float* /*unused*/, int B, int H, int N, int dh, int DP,
-                    hipStream_t s) {
+                    int ld, hipStream_t s) {
   if (B * H == 0 || N == 0) return hipSuccess;
   if (dtype == DT_F32)
     return attn_ref_bwd((const float*)q, (const float*)k, (const float*)v, (const float*)out, (const float*)dout, lse,
-                        (float*)dqkv, delta, B, H, N, dh, DP, s);
-  if (!attn_shape_ok(N, dh, DP, H)) return hipErrorInvalidValue;
+                        (float*)dqkv, delta, B, H, N, dh, DP, ld, s);
+  if (!attn_shape_ok(N, dh, DP, H, ld)) return hipErrorInvalidValue;
+  if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return hipErrorInvalidValue;
 #define SGL_B(DPV)                                                                                             \
   case DPV:                                                                                                    \
     return bwd_launch<DPV>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)out, (const bf16*)dout, \
-                           lse, (bf16*)dqkv, delta, B, H, N, dh, s);
+                           lse, (bf16*)dqkv, delta, B, H, N, dh, ld, s);
   switch (DP) {
     SGL_B(16) SGL_B(32) SGL_B(48) SGL_B(64) SGL_B(80) SGL_B(96)
   }

@@ -73,6 +73,98 @@ hipError_t cast_pad(const float* src, int R, int C, int ld, void* dst, int dst_d
   return hipGetLastError();
 }
 
+// ---- bf16x3 operand splits (compute mode SGL_DTYPE_BF16X3: strict arithmetic on the matrix cores) ------------------
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi).  A product a*b is taken as hi*hi + hi*lo + lo*hi (the
+// lo*lo term, 2^-18 relative, is dropped) by running ONE bf16 MFMA GEMM over a reduction dimension three times as long:
+//   NT (reduction along the row):   A' row = [ hi | hi | lo ],  B' row = [ hi | lo | hi ]      (split3_rows)
+//   TN (reduction down the rows):   A' = [ hi ; hi ; lo ],      B' = [ hi ; lo ; hi ]          (split3_stack)
+// so the generation-6 kernels, their tile order and every fused epilogue are reused unchanged; accumulation is fp32.
+__device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
+  hi = (bf16)x;
+  lo = (bf16)(x - (float)hi);
+}
+
+// dst [R][3*Cs] bf16 (Cs = C rounded up to 8, zero filled); b_side selects the B-operand segment order
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int R, int C, int ld,
+                                                          bf16* __restrict__ dst, int Cs, int b_side) {
+  const int cpr = Cs >> 3;
+  const size_t total = (size_t)R * cpr;
+  const bool vec = ((ld & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int r = (int)(idx / cpr), c0 = (int)(idx - (size_t)r * cpr) * 8;
+    const float* sp = src + (size_t)r * ld + c0;
+    float v[8];
+    if (vec && c0 + 8 <= C) {
+      Vec<float, 4>::ld(sp, v);
+      Vec<float, 4>::ld(sp + 4, v + 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? sp[j] : 0.f;
+    }
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16 h, l;
+      split_bf16(v[j], h, l);
+      hi[j] = h;
+      lo[j] = l;
+    }
+    bf16* dp = dst + (size_t)r * (3 * (size_t)Cs) + c0;
+    *reinterpret_cast<bf16x8*>(dp) = hi;
+    *reinterpret_cast<bf16x8*>(dp + Cs) = b_side ? lo : hi;
+    *reinterpret_cast<bf16x8*>(dp + 2 * (size_t)Cs) = b_side ? hi : lo;
+  }
+}
+
+hipError_t split3_rows(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s) {
+  const size_t total = (size_t)R * (Cs / 8);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split3_rows_kernel, dim3(blocks), dim3(256), 0, s, src, R, C, ld, (bf16*)dst, Cs, b_side);
+  return hipGetLastError();
+}
+
+// dst [3*R][Cs] bf16: rows [0,R) hi, [R,2R) hi (A) / lo (B), [2R,3R) lo (A) / hi (B)
+__global__ __launch_bounds__(256) void split3_stack_kernel(const float* __restrict__ src, int R, int C, int ld,
+                                                           bf16* __restrict__ dst, int Cs, int b_side) {
+  const int cpr = Cs >> 3;
+  const size_t total = (size_t)R * cpr;
+  const bool vec = ((ld & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int r = (int)(idx / cpr), c0 = (int)(idx - (size_t)r * cpr) * 8;
+    const float* sp = src + (size_t)r * ld + c0;
+    float v[8];
+    if (vec && c0 + 8 <= C) {
+      Vec<float, 4>::ld(sp, v);
+      Vec<float, 4>::ld(sp + 4, v + 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? sp[j] : 0.f;
+    }
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16 h, l;
+      split_bf16(v[j], h, l);
+      hi[j] = h;
+      lo[j] = l;
+    }
+    bf16* dp = dst + (size_t)r * Cs + c0;
+    const size_t plane = (size_t)R * Cs;
+    *reinterpret_cast<bf16x8*>(dp) = hi;
+    *reinterpret_cast<bf16x8*>(dp + plane) = b_side ? lo : hi;
+    *reinterpret_cast<bf16x8*>(dp + 2 * plane) = b_side ? hi : lo;
+  }
+}
+
+hipError_t split3_stack(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s) {
+  const size_t total = (size_t)R * (Cs / 8);
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(split3_stack_kernel, dim3(blocks), dim3(256), 0, s, src, R, C, ld, (bf16*)dst, Cs, b_side);
+  return hipGetLastError();
+}
+
 // dst[c][r] = src[r][c]; dst is [Cp][Rp] zero padded.  32x32 LDS tile so both sides stay coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int R, int C, int ld,

@@ -40,6 +40,11 @@ struct sgl_ctx {
   sgl_config cfg;
   int D, I, Ip, L, H, dh, DP, P, K0, Kp, g0, dt;
   size_t es;  // element size of the compute dtype
+  int split = 0;   // SGL_DTYPE_BF16X3: dt == DT_F32 everywhere, GEMMs through the bf16x3 operand split
+  // scratch for the split operands of the GEMM being launched: set by every entry point from the CALLER's buffers (the ctx
+  // owns no memory); calls on one ctx are stream-ordered (siglip_hip.h), so one pair per ctx suffices
+  void* sp_a = nullptr;
+  void* sp_b = nullptr;
   int last_hip = 0;
   // shadow arena layout (config-only)
   size_t sh_wpatch = 0;
@@ -65,6 +70,7 @@ struct Layout {
   size_t a_layer0, a_layer_stride;
   size_t r_stats1, r_h1, r_qkv, r_attn, r_lse, r_xmid, r_stats2, r_h2, r_u, r_a;  // relative to a layer base
   size_t a_pstats, a_lastlp, a_kvh, a_qp, a_probs, a_ao, a_h0, a_hstats, a_hl, a_hu, a_ha;
+  size_t a_spa = 0, a_spb = 0, w_spa = 0, w_spb = 0;   // bf16x3 split operands (forward: in act; backward: in ws)
   size_t act_total;
   // backward scratch (ws)
   size_t w_dx, w_g, w_du, w_dh, w_dqkv, w_delta, w_splitws, w_lnpart, w_cspart, w_dlast, w_gsum, w_csum;
@@ -107,6 +113,15 @@ struct Layout {
     a_hl = a.take((size_t)B * D * es);
     a_hu = a.take((size_t)B * Ip * es);
     a_ha = a.take((size_t)B * Ip * es);
+    // widest GEMM operand: [rows, W] with rows <= max(M, W) on the activation side, [W, max(D, Kp)] on the weight side
+    const size_t Wd = (size_t)round_up((int)(Ip > 3 * D ? Ip : 3 * D) > c->Kp ? (int)(Ip > 3 * D ? Ip : 3 * D) : c->Kp, 8);
+    const size_t sp_act = 3 * (Mz > (size_t)B ? Mz : (size_t)B) * Wd * 2;
+    const size_t sp_wgt = 3 * Wd * (size_t)round_up((int)D > c->Kp ? (int)D : c->Kp, 8) * 2;
+    const size_t sp_bytes = sp_act > sp_wgt ? sp_act : sp_wgt;
+    if (c->split) {
+      a_spa = a.take(sp_bytes);
+      a_spb = a.take(sp_bytes);
+    }
     act_total = a.off;
 
     Bump w;
@@ -131,6 +146,10 @@ struct Layout {
       w_hdqpart = w.take((size_t)B * D * 4);
       w_hdqp = w.take(D * 4);
       w_hdh0 = w.take((size_t)B * D * 4);
+      if (c->split) {
+        w_spa = w.take(sp_bytes);
+        w_spb = w.take(sp_bytes);
+      }
     } else {
       w_dx = w_g = w_du = w_dh = w_dqkv = w_delta = w_splitws = w_lnpart = w_cspart = w_dlast = w_gsum = w_csum = 0;
       w_hg = w_hdu = w_hdh = w_hdao = w_hdqpart = w_hdqp = w_hdh0 = 0;
@@ -165,6 +184,14 @@ inline const char* at(const void* base, size_t off) { return reinterpret_cast<co
 hipError_t gemm_nt(const sgl_ctx* c, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi,
                    int out_dt, const EpiParams& p, hipStream_t s) {
   if (c->dt == DT_BF16) return gemm_nt_bf16(A, lda, B, ldb, M, N, K, epi, out_dt, p, s);
+  if (c->split && M > 0 && N > 0) {   // bf16x3: one MFMA GEMM over [hi|hi|lo] x [hi|lo|hi], three times the reduction length
+    const int Ks = round_up(K, 8);
+    hipError_t e = split3_rows((const float*)A, M, K, lda, c->sp_a, Ks, 0, s);
+    if (e != hipSuccess) return e;
+    e = split3_rows((const float*)B, N, K, ldb, c->sp_b, Ks, 1, s);
+    if (e != hipSuccess) return e;
+    return gemm_nt_bf16(c->sp_a, 3 * Ks, c->sp_b, 3 * Ks, M, N, 3 * Ks, epi, out_dt, p, s);
+  }
   return gemm_f32_generic((const float*)A, lda, 1, (const float*)B, ldb, 1, M, N, K, epi, out_dt, p, s);
 }
 
@@ -184,6 +211,20 @@ hipError_t gemm_tn(const sgl_ctx* c, const void* A, int lda, const void* B, int 
     if (splits > 16) splits = 16;
     return gemm_tn_bf16(A, lda, B, ldb, Mred, N1, N2, splits, p, s, reinterpret_cast<float*>(split_ws), split_ws_bytes);
   }
+  if (c->split && Mred > 0 && N1 > 0 && N2 > 0) {   // bf16x3: [hi;hi;lo]^T x [hi;lo;hi], reduction over 3*Mred rows
+    const int l1 = round_up(N1, 8), l2 = round_up(N2, 8);
+    hipError_t e = split3_stack((const float*)A, Mred, N1, lda, c->sp_a, l1, 0, s);
+    if (e != hipSuccess) return e;
+    e = split3_stack((const float*)B, Mred, N2, ldb, c->sp_b, l2, 1, s);
+    if (e != hipSuccess) return e;
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    int splits = (512 + tiles - 1) / tiles;
+    const int max_splits = (3 * Mred) / 512 > 0 ? (3 * Mred) / 512 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+    return gemm_tn_bf16(c->sp_a, l1, c->sp_b, l2, 3 * Mred, N1, N2, splits, p, s, reinterpret_cast<float*>(split_ws),
+                        split_ws_bytes);
+  }
   return gemm_f32_generic((const float*)A, 1, lda, (const float*)B, 1, ldb, N1, N2, Mred, EPI_F32, DT_F32, p, s);
 }
 
@@ -200,7 +241,7 @@ bool shape_ok(const sgl_ctx* c, int B, int H, int W) {
 // =======================================================================================================
 extern "C" {
 
-int sgl_abi_version(void) { return 2; }
+int sgl_abi_version(void) { return 3; }
 
 const char* sgl_status_string(int status) {
   switch (status) {
@@ -222,7 +263,9 @@ sgl_ctx* sgl_create(const sgl_config* cfg) {
   if (cfg->intermediate_size <= 0 || cfg->num_layers < 0 || cfg->num_layers > 128 || cfg->patch_size <= 0 ||
       cfg->native_grid <= 0)
     return nullptr;
-  if (cfg->compute_dtype != SGL_DTYPE_F32 && cfg->compute_dtype != SGL_DTYPE_BF16) return nullptr;
+  if (cfg->compute_dtype != SGL_DTYPE_F32 && cfg->compute_dtype != SGL_DTYPE_BF16 &&
+      cfg->compute_dtype != SGL_DTYPE_BF16X3)
+    return nullptr;
   sgl_ctx* c = new (std::nothrow) sgl_ctx();
   if (!c) return nullptr;
   c->cfg = *cfg;
@@ -237,7 +280,8 @@ sgl_ctx* sgl_create(const sgl_config* cfg) {
   c->K0 = 3 * c->P * c->P;
   c->Kp = round_up(c->K0, 64);
   c->g0 = cfg->native_grid;
-  c->dt = cfg->compute_dtype;
+  c->split = cfg->compute_dtype == SGL_DTYPE_BF16X3;
+  c->dt = c->split ? DT_F32 : cfg->compute_dtype;
   c->es = dtype_size(c->dt);
   const size_t es = c->es, D = c->D, Ip = c->Ip;
   Bump b;
@@ -446,6 +490,10 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
   const int D = ctx->D, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh, DP = ctx->DP;
   char* act = train ? reinterpret_cast<char*>(saved) : at(ws, lay.ws_act_off);
   auto hs = [&](int l) { return hs_slots[l]; };
+  if (ctx->split) {
+    ctx->sp_a = act + lay.a_spa;
+    ctx->sp_b = act + lay.a_spb;
+  }
 
   // ---- embeddings
   if (channels_last == 2) {   // ready patch-major operand (sgl_op_preprocess): keep a copy where backward expects it
@@ -481,6 +529,11 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
     float* xmid = reinterpret_cast<float*>(lb + lay.r_xmid);
     CK(layernorm_fwd(x, lw.ln1_w, lw.ln1_b, lb + lay.r_h1, dt, D, st1, st1 + M, M, D, ctx->cfg.layer_norm_eps, s));
     {
+      // head-major scatter [3][B][H][N][DP] in the GEMM epilogue (EPI_QKV).  Round 3 measured the alternative the kernels
+      // also support (ld_qkv > 0: plain token-major [M][3D] store, attention gathers each head's 144-byte row segments):
+      // QKV GEMM 853 -> 754 us per launch at B = 128, but attention forward +5.8 % and backward +5.9 % (every DMA instruction
+      // touches 14 cache lines instead of 8, and K/V are re-read by six workgroups per head and three kernels): +0.75 ms
+      // per step net, so the 144-byte granularity is paid once, on the write side.
       EpiParams p;
       p.out = lb + lay.r_qkv;
       p.bias = reinterpret_cast<const float*>(at(shadow, sl.bqkv));
@@ -495,7 +548,7 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
       const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
       char* q = lb + lay.r_qkv;
       CK(attn_fwd(q, q + hsz, q + 2 * hsz, dt, lb + lay.r_attn, reinterpret_cast<float*>(lb + lay.r_lse), B, Hh, N, dh,
-                  DP, s));
+                  DP, 0, s));
     }
     {
       EpiParams p;
@@ -650,6 +703,10 @@ int sgl_backward_begin_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, true);
   RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  if (ctx->split) {
+    ctx->sp_a = at(ws, lay.w_spa);
+    ctx->sp_b = at(ws, lay.w_spb);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh,
             DP = ctx->DP;
@@ -778,6 +835,10 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, true);
   RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  if (ctx->split) {
+    ctx->sp_a = at(ws, lay.w_spa);
+    ctx->sp_b = at(ws, lay.w_spb);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, M = lay.M, N = lay.N, dt = ctx->dt, Hh = ctx->H, dh = ctx->dh,
             DP = ctx->DP;
@@ -844,7 +905,7 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
     const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
     const char* q = lb + lay.r_qkv;
     CK(attn_bwd(q, q + hsz, q + 2 * hsz, lb + lay.r_attn, dhb, reinterpret_cast<const float*>(lb + lay.r_lse), dt, dqkv,
-                reinterpret_cast<float*>(at(ws, lay.w_delta)), nullptr, B, Hh, N, dh, DP, s));
+                reinterpret_cast<float*>(at(ws, lay.w_delta)), nullptr, B, Hh, N, dh, DP, 0, s));
   }
   {
     float* gw[3] = {lg.q_w, lg.k_w, lg.v_w};
@@ -886,6 +947,10 @@ int sgl_backward_embed(sgl_ctx* ctx, const sgl_weights* w, const sgl_grads* g, i
   if (!shape_ok(ctx, B, H, W)) return SGL_ERR_BAD_SHAPE;
   Layout lay(ctx, B, H, W, true);
   RET(check_bwd_args(ctx, lay, saved, saved_bytes, ws, ws_bytes));
+  if (ctx->split) {
+    ctx->sp_a = at(ws, lay.w_spa);
+    ctx->sp_b = at(ws, lay.w_spb);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int D = ctx->D, M = lay.M, N = lay.N;
   const int acc = g->accumulate;
@@ -995,15 +1060,15 @@ int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb,
 }
 
 int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
-                    int head_dim, int head_dim_pad, sgl_stream stream) {
-  CKV(attn_fwd(q, k, v, dtype, out, lse, B, H, N, head_dim, head_dim_pad, (hipStream_t)stream));
+                    int head_dim, int head_dim_pad, int ld_qkv, sgl_stream stream) {
+  CKV(attn_fwd(q, k, v, dtype, out, lse, B, H, N, head_dim, head_dim_pad, ld_qkv, (hipStream_t)stream));
   return SGL_OK;
 }
 
 int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, void* dqkv, float* delta_scratch, int B, int H, int N, int head_dim,
-                    int head_dim_pad, sgl_stream stream) {
-  CKV(attn_bwd(q, k, v, out, dout, lse, dtype, dqkv, delta_scratch, nullptr, B, H, N, head_dim, head_dim_pad,
+                    int head_dim_pad, int ld_qkv, sgl_stream stream) {
+  CKV(attn_bwd(q, k, v, out, dout, lse, dtype, dqkv, delta_scratch, nullptr, B, H, N, head_dim, head_dim_pad, ld_qkv,
                (hipStream_t)stream));
   return SGL_OK;
 }

@@ -385,9 +385,15 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
                                 : launch_nt<E, float>(A, lda, B, ldb, M, N, K, p, s);
   switch (epi) {
     SGL_CASE(EPI_STORE)
-    case EPI_BIAS_GELU: return launch_nt<EPI_BIAS_GELU, bf16>(A, lda, B, ldb, M, N, K, p, s);
-    case EPI_QKV: return launch_nt<EPI_QKV, bf16>(A, lda, B, ldb, M, N, K, p, s);
-    case EPI_GELU_BWD: return launch_nt<EPI_GELU_BWD, bf16>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_BIAS_GELU:
+      return out_dtype == DT_BF16 ? launch_nt<EPI_BIAS_GELU, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt<EPI_BIAS_GELU, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
+    case EPI_QKV:
+      return out_dtype == DT_BF16 ? launch_nt<EPI_QKV, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt<EPI_QKV, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
+    case EPI_GELU_BWD:
+      return out_dtype == DT_BF16 ? launch_nt<EPI_GELU_BWD, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt<EPI_GELU_BWD, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
     case EPI_RES_F32: return launch_nt<EPI_RES_F32, float>(A, lda, B, ldb, M, N, K, p, s);
     case EPI_POS_F32: return launch_nt<EPI_POS_F32, float>(A, lda, B, ldb, M, N, K, p, s);
     case EPI_F32: return launch_nt<EPI_F32, float>(A, lda, B, ldb, M, N, K, p, s);

@@ -855,9 +855,15 @@ hipError_t gemm_nt2_bf16(const void* A_, int lda, const void* B_, int ldb, int M
     case EPI_STORE:
       return out_dtype == DT_BF16 ? launch_nt2<EPI_STORE, bf16>(A, lda, B, ldb, M, N, K, p, s)
                                   : launch_nt2<EPI_STORE, float>(A, lda, B, ldb, M, N, K, p, s);
-    case EPI_BIAS_GELU: return launch_nt2<EPI_BIAS_GELU, bf16>(A, lda, B, ldb, M, N, K, p, s);
-    case EPI_QKV: return launch_nt2<EPI_QKV, bf16>(A, lda, B, ldb, M, N, K, p, s);
-    case EPI_GELU_BWD: return launch_nt2<EPI_GELU_BWD, bf16>(A, lda, B, ldb, M, N, K, p, s);
+    case EPI_BIAS_GELU:
+      return out_dtype == DT_BF16 ? launch_nt2<EPI_BIAS_GELU, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt2<EPI_BIAS_GELU, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
+    case EPI_QKV:
+      return out_dtype == DT_BF16 ? launch_nt2<EPI_QKV, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt2<EPI_QKV, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
+    case EPI_GELU_BWD:
+      return out_dtype == DT_BF16 ? launch_nt2<EPI_GELU_BWD, bf16>(A, lda, B, ldb, M, N, K, p, s)
+                                  : launch_nt2<EPI_GELU_BWD, float>(A, lda, B, ldb, M, N, K, p, s);   // bf16x3 strict mode
     case EPI_RES_F32: return launch_nt2<EPI_RES_F32, float>(A, lda, B, ldb, M, N, K, p, s);
     case EPI_POS_F32: return launch_nt2<EPI_POS_F32, float>(A, lda, B, ldb, M, N, K, p, s);
     case EPI_F32: return launch_nt2<EPI_F32, float>(A, lda, B, ldb, M, N, K, p, s);

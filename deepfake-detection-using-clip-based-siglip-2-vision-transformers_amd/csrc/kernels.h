@@ -72,6 +72,9 @@ hipError_t cast_pad(const float* src, int R, int C, int lds_, void* dst, int dst
 // dst[c][r] (row stride ldd) = cast(src[r][c]) for c < Cp, r < Rp, zero outside
 hipError_t cast_transpose_pad(const float* src, int R, int C, int lds_, void* dst, int dst_dtype, int Cp, int Rp,
                               int ldd, hipStream_t s);
+// bf16x3 operand splits (elementwise.hip): Cs = round_up(C, 8); dst holds 3 * R * Cs bf16
+hipError_t split3_rows(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s);
+hipError_t split3_stack(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s);
 int colsum_chunks(int M);
 // out[j] (+)= sum_r in[r][j] for j < n_out (n_out <= N; N, ld multiples of 8; columns up to N are read)
 hipError_t colsum(const void* in, int dtype, int ld, int M, int N, int n_out, float* partial /*[chunks][N]*/,
@@ -110,13 +113,15 @@ hipError_t gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, int Mred
                         const EpiParams& p, hipStream_t s, float* split_ws = nullptr, size_t split_ws_bytes = 0);
 
 // ---- attention.hip -------------------------------------------------------------------------------------
-// q,k,v: head-major [B][H][N][DP]; out: token-major [B*N][H*dh]; lse: [B][H][N] (natural log units)
+// q,k,v: ld_qkv > 0: token-major [B*N][ld_qkv] column blocks (head h of row r at r*ld_qkv + h*dh; the QKV projection's
+// plain output, q/k/v = its three D-wide column blocks); ld_qkv == 0: head-major [B][H][N][DP] with zero pad columns.
+// out: token-major [B*N][H*dh]; lse: [B][H][N] (natural log units)
 hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void* out, float* lse, int B, int H,
-                    int N, int dh, int DP, hipStream_t s);
+                    int N, int dh, int DP, int ld_qkv, hipStream_t s);
 // dout: token-major [B*N][H*dh] (T); dqkv: token-major [B*N][3*H*dh] (T); delta: scratch of 2*B*H*N floats
 hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, int dtype, void* dqkv, float* delta, float* reserved, int B, int H, int N,
-                    int dh, int DP, hipStream_t s);
+                    int dh, int DP, int ld_qkv, hipStream_t s);
 size_t attn_bwd_scratch_bytes(int dtype, int B, int H, int N, int dh, int DP);
 
 }  // namespace sgl

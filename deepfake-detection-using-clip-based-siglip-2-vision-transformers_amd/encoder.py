@@ -436,8 +436,12 @@ class SiglipVisionModelHIP(nn.Module):
     def __init__(self, config, compute_dtype: str = "bf16"):
         super().__init__()
         self.config = get_config(config)
-        if compute_dtype not in ("bf16", "fp32"):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        # "bf16": the benchmarked mode (bf16 MFMA operands, fp32 accumulate / residual stream / statistics);
+        # "fp32": strict reference arithmetic (plain fp32 FMAs, no matrix cores): tightest parity, slow;
+        # "bf16x3": strict mode on the matrix cores (every GEMM as one bf16 MFMA GEMM over hi/lo-split operands, fp32
+        #           accumulate; ~2^-17 relative per product): the north-star "logits within 1e-3" at MFMA speed
+        if compute_dtype not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError("compute_dtype must be 'bf16', 'fp32' or 'bf16x3'")
         self.compute_dtype = compute_dtype
         cfg = self.config
         self.embeddings = _EmbeddingParams(cfg)
@@ -697,7 +701,8 @@ class SiglipVisionModelHIP(nn.Module):
             cfg = self.config
             c = _lib.SglConfig(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
                                cfg.patch_size, cfg.native_grid, cfg.layer_norm_eps,
-                               _lib.SGL_DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.SGL_DTYPE_F32,
+                               {"bf16": _lib.SGL_DTYPE_BF16, "fp32": _lib.SGL_DTYPE_F32,
+                                "bf16x3": _lib.SGL_DTYPE_BF16X3}[self.compute_dtype],
                                1 if self.use_head else 0)
             ctx = lib.sgl_create(C.byref(c))
             if not ctx:

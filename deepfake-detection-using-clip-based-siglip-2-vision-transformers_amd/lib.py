@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGL_LIB_PATH") or os.path.join(_HERE, "libsiglip_hip.so")  # override: developer A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "siglip_hip.h")
 
-SGL_DTYPE_F32, SGL_DTYPE_BF16 = 0, 1
+SGL_DTYPE_F32, SGL_DTYPE_BF16, SGL_DTYPE_BF16X3 = 0, 1, 2
 EPI_STORE, EPI_BIAS_GELU, EPI_RES_F32, EPI_QKV, EPI_GELU_BWD, EPI_POS_F32, EPI_F32 = range(7)
 STATUS = {0: "ok", -1: "bad shape", -2: "unsupported configuration", -3: "buffer too small", -4: "HIP error",
           -5: "null pointer"}
@@ -123,8 +123,8 @@ def load():
                                     i, i, i, _fp])
     _sig(lib, "sgl_op_gemm_tn", i, [i, _fp, i, _fp, i, i, i, i, i, _fp, i, i, _fp])
     _sig(lib, "sgl_op_gemm_tn_ws", i, [i, _fp, i, _fp, i, i, i, i, i, _fp, i, i, _fp, sz, _fp])
-    _sig(lib, "sgl_op_attn_fwd", i, [i, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, _fp])
-    _sig(lib, "sgl_op_attn_bwd", i, [i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, _fp])
+    _sig(lib, "sgl_op_attn_fwd", i, [i, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, i, _fp])
+    _sig(lib, "sgl_op_attn_bwd", i, [i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, i, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_colsum", i, [i, _fp, i, i, i, _fp, i, _fp, sz, _fp])
     _sig(lib, "sgl_op_im2col", i, [_fp, i, _fp, i, i, i, i, i, i, _fp])
     _sig(lib, "sgl_op_pos_resize", i, [_fp, i, _fp, i, i, i, _fp])

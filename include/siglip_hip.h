@@ -29,7 +29,7 @@ extern "C" {
 typedef struct sgl_ctx sgl_ctx;
 typedef void* sgl_stream; /* hipStream_t */
 
-enum { SGL_DTYPE_F32 = 0, SGL_DTYPE_BF16 = 1 };
+enum { SGL_DTYPE_F32 = 0, SGL_DTYPE_BF16 = 1, SGL_DTYPE_BF16X3 = 2 };
 
 typedef enum {
   SGL_OK = 0,
@@ -50,7 +50,11 @@ typedef struct {
   int native_grid;        /* image_size / p : side of the stored position table */
   float layer_norm_eps;   /* 1e-6 */
   int compute_dtype;      /* SGL_DTYPE_BF16: bf16 MFMA operands, fp32 accumulate / residual stream / statistics;
-                             SGL_DTYPE_F32 : strict fp32 everywhere (parity mode) */
+                             SGL_DTYPE_F32 : strict fp32 everywhere (parity mode; plain fp32 FMAs, no matrix cores);
+                             SGL_DTYPE_BF16X3: strict mode ON the matrix cores: activations, weights and buffers exactly as
+                                in SGL_DTYPE_F32, but every GEMM runs as one bf16 MFMA GEMM over split operands
+                                (x = hi + lo; hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-17 relative per product) and
+                                attention as fp32 MFMA; meets "logits within 1e-3" at a fraction of SGL_DTYPE_F32's cost */
   int use_head;           /* attention-pool head present (vision_use_head) */
 } sgl_config;
 
@@ -199,12 +203,19 @@ int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, in
  * suffices for the 256x256-tile kernel) the splits are summed in a fixed order -> bitwise reproducible, no fp32 atomics. */
 int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
                       float* out, int ldo, int accumulate, float* scratch, size_t scratch_bytes, sgl_stream stream);
+/* Scaled-dot-product attention of one block (TF:modeling_siglip.py:227-247,288-301), all heads and images in one launch.
+ * ld_qkv > 0 (what the encoder uses since ABI 3): q, k, v point at the three column blocks of the QKV projection's
+ *   token-major output [B*N][ld_qkv]; head h of token row r is the head_dim elements at r*ld_qkv + h*head_dim (16-byte
+ *   aligned: head_dim % 8 == 0, ld_qkv % 8 == 0, pointers 16-byte aligned).  Nothing is padded in memory.
+ * ld_qkv == 0: legacy head-major [B][H][N][head_dim_pad] matrices whose pad columns are zero (EPI_QKV's layout).
+ * out: token-major [B*N][H*head_dim]; lse: [B][H][N]. */
 int sgl_op_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int N,
-                    int head_dim, int head_dim_pad, sgl_stream stream);
-/* delta_scratch: 2 * B * H * N floats (per query and head the pair {-lse * log2 e, -rowsum(dO * O) / sqrt(head_dim)}). */
+                    int head_dim, int head_dim_pad, int ld_qkv, sgl_stream stream);
+/* dqkv: token-major [B*N][3*H*head_dim].  delta_scratch: 2 * B * H * N floats (per query and head the pair
+ * {-lse * log2 e, -rowsum(dO * O) / sqrt(head_dim)}; ABI 1 took B * H * N floats here). */
 int sgl_op_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout,
                     const float* lse, void* dqkv, float* delta_scratch, int B, int H, int N, int head_dim,
-                    int head_dim_pad, sgl_stream stream);
+                    int head_dim_pad, int ld_qkv, sgl_stream stream);
 int sgl_op_colsum(int dtype, const void* in, int ld, int M, int N, float* out, int accumulate, float* scratch,
                   size_t scratch_bytes, sgl_stream stream);
 int sgl_op_im2col(const float* pixels, int channels_last, void* out, int out_dtype, int B, int H, int W, int P, int Kp,

@@ -9,14 +9,21 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 H, N, dh, DP = 16, 729, 72, 80
 D = H * dh
 st = torch.cuda.current_stream()
-qkv = torch.zeros(3, B, H, N, DP, device="cuda", dtype=torch.bfloat16)
-qkv[..., :dh] = torch.randn(3, B, H, N, dh, device="cuda").bfloat16()
+LAYOUT = os.environ.get("ATT_LAYOUT", "token")   # token: [B*N, 3D] as the encoder's QKV GEMM writes it; head: [3,B,H,N,DP]
+if LAYOUT == "token":
+    tok = torch.randn(B * N, 3 * D, device="cuda").bfloat16()
+    qkv = [tok[:, j * D:] for j in range(3)]
+    LD = 3 * D
+else:
+    qkv = torch.zeros(3, B, H, N, DP, device="cuda", dtype=torch.bfloat16)
+    qkv[..., :dh] = torch.randn(3, B, H, N, dh, device="cuda").bfloat16()
+    LD = 0
 out = torch.empty(B * N, D, device="cuda", dtype=torch.bfloat16)
 dout = torch.randn(B * N, D, device="cuda").bfloat16()
 lse = torch.empty(B, H, N, device="cuda"); delta = torch.empty(2, B, H, N, device="cuda")
 dqkv = torch.empty(B * N, 3 * D, device="cuda", dtype=torch.bfloat16)
-def fwd(): assert lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, N, dh, DP, st.cuda_stream) == 0
-def bwd(): assert lib.sgl_op_attn_bwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), B, H, N, dh, DP, st.cuda_stream) == 0
+def fwd(): assert lib.sgl_op_attn_fwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), lse.data_ptr(), B, H, N, dh, DP, LD, st.cuda_stream) == 0
+def bwd(): assert lib.sgl_op_attn_bwd(1, qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), B, H, N, dh, DP, LD, st.cuda_stream) == 0
 for name, fn, fl in (("fwd", fwd, 4.0), ("bwd", bwd, 10.0)):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg, hiplib):
         assert fn.argtypes is not None, f"{name} has no ctypes signature"
         assert len(fn.argtypes) == nargs, f"{name}: header has {nargs} parameters, binding {len(fn.argtypes)}"
     assert set(pkg.lib.declared_symbols()) == set(protos)
-    assert hiplib.sgl_abi_version() == 2
+    assert hiplib.sgl_abi_version() == 3
     assert hiplib.sgl_status_string(0) == b"ok" and hiplib.sgl_status_string(-3) == b"buffer too small"
 
 

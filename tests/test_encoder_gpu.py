@@ -22,19 +22,21 @@ def build(pkg, cfg_name, seed, mode):
 
 
 @pytest.mark.parametrize("case", gu.CASES)
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
     rec = gu.load(case)
     m = gu.meta(rec)
     model = build(pkg, m["config"], m["seed"], mode)
     x = pkg.weights.seeded_pixels(m["batch"], m["res"], m["res"], seed=m["seed"] + 1000).cuda()
     out = model(pixel_values=x, output_hidden_states=True, interpolate_pos_encoding=m["interp"])
-    strict = mode == "fp32"
+    strict = mode in ("fp32", "bf16x3")
+    # bf16x3 (strict mode on the matrix cores: split-bf16 GEMMs, ~2^-17 per product) gets X3 times the fp32 mode's bounds
+    X3 = 16.0 if mode == "bf16x3" else 1.0
 
     def tol(prefix):
         """fp32: fixed (2x the measured 6.2e-6 / 1.4e-6 relative); bf16: 3x what HF under bf16 autocast does on this tensor."""
         if strict:
-            return 2e-5, 0.0
+            return 2e-5 * X3, 0.0
         return 3.0 * float(rec["bf16ac." + prefix + ".maxerr"]) + 1e-6, 1e-3     # (rtol only feeds the checksum check)
     errs = {}
     errs["pooled"] = gu.compare(rec, "pooler_output", out.pooler_output.detach().cpu(), *tol("pooler_output"))
@@ -47,7 +49,7 @@ def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
     # same scalar as oracle.probe_loss, built on the GPU tensors
     loss = _probe_loss(o, m["taps"])
     hf_loss_err = abs(float(rec["bf16ac.loss"]) - float(rec["loss"]))
-    assert abs(loss.item() - float(rec["loss"])) <= (2e-5 * max(1.0, abs(float(rec["loss"]))) if strict
+    assert abs(loss.item() - float(rec["loss"])) <= (2e-5 * X3 * max(1.0, abs(float(rec["loss"]))) if strict
                                                       else max(3.0 * hf_loss_err, 0.05 * max(1.0, abs(float(rec["loss"])))))
     loss.backward()
     sd = dict(model.named_parameters())
@@ -61,9 +63,9 @@ def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
                 # what is left is rounding noise of sum_tokens(dK), bounded relative to the d q_proj.weight scale
                 qw = "grad.encoder.layers.0.self_attn.q_proj.weight"
                 qscale = float(abs(rec[qw + ".full"] if qw + ".full" in rec else rec[qw + ".samples"]).max())
-                a_tol, r_tol = (6e-5 if strict else 2e-2) * qscale, (0.0 if strict else 1e-2)
+                a_tol, r_tol = (6e-5 * X3 if strict else 2e-2) * qscale, (0.0 if strict else 1e-2)
             elif strict:
-                a_tol, r_tol = 1e-7, 6e-5          # measured <= 1e-5 of max-norm
+                a_tol, r_tol = 1e-7, 6e-5 * X3     # measured <= 1e-5 of max-norm (fp32)
             else:                                  # 3x what HF under bf16 autocast does on this gradient
                 a_tol, r_tol = 3.0 * float(rec["bf16ac.grad." + name + ".maxerr"]) + 1e-7, 1e-2
             errs["g:" + name] = gu.compare(rec, "grad." + name, sd[name].grad.detach().cpu(), a_tol, r_tol)

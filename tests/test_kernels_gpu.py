@@ -208,17 +208,28 @@ def attn_reference(q, k, v, dout):
 @pytest.mark.parametrize("B,H,N,dh", [(1, 2, 4, 16), (2, 2, 9, 72), (2, 4, 49, 16), (1, 3, 196, 64), (2, 16, 729, 72),
                                       (1, 2, 1024, 72), (1, 2, 130, 32)])
 @pytest.mark.parametrize("dtype", [BF16, F32])
-def test_attention_fwd_bwd(lib, B, H, N, dh, dtype):
+@pytest.mark.parametrize("layout", ["token", "head"])
+def test_attention_fwd_bwd(lib, B, H, N, dh, dtype, layout):
+    """layout "token": q | k | v are the column blocks of one token-major [B*N, 3D] matrix (what the encoder's QKV GEMM
+    writes; each head's dh-element row segments are gathered by the kernels, nothing padded in memory), with NaN in a
+    4th column block behind v to catch any read past a head's segment; "head": the legacy [B,H,N,DP] matrices."""
     torch.manual_seed(N + dh)
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
     DP = (dh + 15) // 16 * 16
     D = H * dh
     qkv = torch.zeros(3, B, H, N, DP, device="cuda", dtype=tdt)
     qkv[..., :dh] = (torch.randn(3, B, H, N, dh, device="cuda") * 1.2).to(tdt)
+    if layout == "token":
+        ld = 3 * D + 8
+        tok = torch.full((B * N, ld), float("nan"), device="cuda", dtype=tdt)
+        tok[:, :3 * D] = qkv[..., :dh].permute(1, 3, 0, 2, 4).reshape(B * N, 3 * D)
+        ptrs = [P(tok) + j * D * tok.element_size() for j in range(3)]
+    else:
+        ld, ptrs = 0, [P(qkv[0]), P(qkv[1]), P(qkv[2])]
     dout_tok = torch.randn(B * N, D, device="cuda").to(tdt)
     out = torch.full((B * N, D), float("nan"), device="cuda", dtype=tdt)
     lse = torch.empty(B, H, N, device="cuda")
-    ok(lib.sgl_op_attn_fwd(dtype, P(qkv[0]), P(qkv[1]), P(qkv[2]), P(out), P(lse), B, H, N, dh, DP, stream()))
+    ok(lib.sgl_op_attn_fwd(dtype, ptrs[0], ptrs[1], ptrs[2], P(out), P(lse), B, H, N, dh, DP, ld, stream()))
     dout_h = dout_tok.view(B, N, H, dh).permute(0, 2, 1, 3)
     o_ref, lse_ref, dq, dk, dv = attn_reference(qkv[0][..., :dh], qkv[1][..., :dh], qkv[2][..., :dh], dout_h)
     o_tok = o_ref.permute(0, 2, 1, 3).reshape(B * N, D)
@@ -228,8 +239,8 @@ def test_attention_fwd_bwd(lib, B, H, N, dh, dtype):
     dqkv = torch.full((B * N, 3 * D), float("nan"), device="cuda", dtype=tdt)
     delta = torch.empty(2, B, H, N, device="cuda")   # scratch: 2*B*H*N floats (include/siglip_hip.h)
     # the backward consumes the forward's own output (as the encoder does)
-    ok(lib.sgl_op_attn_bwd(dtype, P(qkv[0]), P(qkv[1]), P(qkv[2]), P(out), P(dout_tok), P(lse), P(dqkv), P(delta), B, H,
-                           N, dh, DP, stream()))
+    ok(lib.sgl_op_attn_bwd(dtype, ptrs[0], ptrs[1], ptrs[2], P(out), P(dout_tok), P(lse), P(dqkv), P(delta), B, H,
+                           N, dh, DP, ld, stream()))
     got = dqkv.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).float()
     btol = 3e-2 if dtype == BF16 else 5e-5
     assert relerr(got[0], dq) < btol, "dQ"
@@ -248,7 +259,7 @@ def test_attention_softmax_rescale_branch(lib):
     qkv = qkv.to(torch.bfloat16)
     out = torch.empty(N, dh, device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(B, H, N, device="cuda")
-    ok(lib.sgl_op_attn_fwd(BF16, P(qkv[0]), P(qkv[1]), P(qkv[2]), P(out), P(lse), B, H, N, dh, DP, stream()))
+    ok(lib.sgl_op_attn_fwd(BF16, P(qkv[0]), P(qkv[1]), P(qkv[2]), P(out), P(lse), B, H, N, dh, DP, 0, stream()))
     q, k, v = (t.float() for t in qkv)
     ref = torch.softmax((q @ k.transpose(-1, -2)) / 8.0, -1) @ v
     assert relerr(out, ref[0, 0]) < 1.5e-2

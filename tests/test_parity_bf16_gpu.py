@@ -122,11 +122,14 @@ def full_depth_reference(pkg, oracle):
 # tolerances: relative L2 per tensor; fp32 mode is the north-star "logits within 1e-3" path, bf16 the benchmarked one.
 # Values are 2x what the MI355X run measured (printed by the test).
 # measured (r2): fp32 act 1.4e-6, grads <= 6.8e-6, pooled 7.0e-6 abs; bf16 act 5.4e-3, grads <= 1.03e-2, pooled 2.2e-2 abs
+# bf16x3 = strict mode on the matrix cores (split-bf16 GEMMs; attention in fp32): its bound is the north-star one, pooled
+# output within 1e-3 abs of the fp32 reference, plus 2x what round 3 measured for the other tensors.
 FULL_TOL = {"fp32": dict(act=3e-6, grad=1.4e-5, pooled_abs=2e-5, loss=2e-6),
+            "bf16x3": dict(act=1e-4, grad=4e-4, pooled_abs=1e-3, loss=1e-4),
             "bf16": dict(act=1.1e-2, grad=2.1e-2, pooled_abs=4.4e-2, loss=8e-3)}
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
 def test_full_depth_forward_backward_vs_oracle(mode, pkg, hiplib, full_depth_reference):
     """so400m-patch14-384, all 27 blocks, B=2: outputs, taps 1/14/27 and gradients of the patch embedding, blocks 0, 13,
     26 and the pooling head against the fp32 CPU oracle (bf16 drift through 27 layers of backward is pinned here)."""
@@ -156,7 +159,7 @@ def test_full_depth_forward_backward_vs_oracle(mode, pkg, hiplib, full_depth_ref
     for k, v in gerrs.items():
         assert v <= tol["grad"], (k, v)
     assert abs(loss.item() - ref["loss"]) <= tol["loss"] * max(1.0, abs(ref["loss"]))
-    if mode == "fp32":
+    if mode in ("fp32", "bf16x3"):
         assert pooled_abs < 1e-3     # the north-star bound ("logits within 1e-3 of the HF reference"), 140x margin
 
 
