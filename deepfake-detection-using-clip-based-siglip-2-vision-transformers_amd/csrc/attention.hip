@@ -28,6 +28,9 @@
 
 namespace sgl {
 
+hipError_t attn_f32_fwd(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
+hipError_t attn_f32_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                        float*, int, int, int, int, int, int, hipStream_t);
 hipError_t attn_ref_fwd(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
 hipError_t attn_ref_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*,
                         float*, int, int, int, int, int, int, hipStream_t);
@@ -144,7 +147,7 @@ __device__ __forceinline__ uint32_t att_chunk_off(int cidx, int rows, int SC, in
 // ======================================================================================================
 // forward
 // ======================================================================================================
-template <int DP>
+template <int DP, bool TOK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int B, int H, int N, int dh, int ld,
@@ -163,7 +166,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (!head_block((N + 127) / 128, B * H, bh, xb)) return;
   const int b = bh / H, hd = bh - b * H;
   const int q0 = xb * 128 + w * 32;
-  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  HeadSrc src = head_src(TOK ? ld : 0, b, hd, H, N, dh, DP);
+  if constexpr (!TOK) {   // head-major: compile-time row geometry (the encoder's path keeps its constant-folded addressing)
+    src.rowbytes = (uint32_t)DP * 2u;
+    src.nc = (uint32_t)DP / 8u;
+  }
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + src.base, src.bytes);
   const u32x4 dk_ = att_desc(K + src.base, src.bytes);
   const u32x4 dv_ = att_desc(V + src.base, src.bytes);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // ======================================================================================================
 // backward: dK, dV   (wave owns 32 keys; sweeps 32-query tiles staged in LDS)
 // ======================================================================================================
-template <int DP>
+template <int DP, bool TOK>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                              const bf16* __restrict__ V, const bf16* __restrict__ dO,
                                                              const float* __restrict__ aux, bf16* __restrict__ dqkv,
@@ -315,7 +322,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
   const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
   const int key0 = xb * 128 + w * 32;
-  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  HeadSrc src = head_src(TOK ? ld : 0, b, hd, H, N, dh, DP);
+  if constexpr (!TOK) {   // head-major: compile-time row geometry (the encoder's path keeps its constant-folded addressing)
+    src.rowbytes = (uint32_t)DP * 2u;
+    src.nc = (uint32_t)DP / 8u;
+  }
   const __amdgpu_buffer_rsrc_t rk = make_rsrc(K + src.base, src.bytes);
   const __amdgpu_buffer_rsrc_t rv = make_rsrc(V + src.base, src.bytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const bf16* __restr
 // ======================================================================================================
 // backward: dQ   (wave owns 32 queries; sweeps 32-key tiles staged in LDS)
 // ======================================================================================================
-template <int DP>
+template <int DP, bool TOK>
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, const bf16* __restrict__ O,
                                                             const bf16* __restrict__ dO, const float* __restrict__ lse,
@@ -522,7 +533,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const bf16* __restri
   const int b = bh / H, hd = bh - b * H;
   const int D = H * dh;
   const int q0 = xb * 128 + w * 32;
-  const HeadSrc src = head_src(ld, b, hd, H, N, dh, DP);
+  HeadSrc src = head_src(TOK ? ld : 0, b, hd, H, N, dh, DP);
+  if constexpr (!TOK) {   // head-major: compile-time row geometry (the encoder's path keeps its constant-folded addressing)
+    src.rowbytes = (uint32_t)DP * 2u;
+    src.nc = (uint32_t)DP / 8u;
+  }
   const __amdgpu_buffer_rsrc_t rq = make_rsrc(Q + src.base, src.bytes);
   const bf16* dOb = dO + (size_t)b * N * D + hd * dh;
   const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dOb, (uint32_t)(((size_t)(N - 1) * D + dh) * 2));
@@ -696,8 +711,12 @@ static hipError_t fwd_launch(const bf16* q, const bf16* k, const bf16* v, bf16* 
   using C = AttnCfg<DP>;
   constexpr int smem = 2 * (64 * C::RSTR + 64 * C::TSTR);
   const float scale = 1.0f / sqrtf((float)dh);
-  hipLaunchKernelGGL(attn_fwd_kernel<DP>, head_grid((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse, B, H, N,
-                     dh, ld, scale * 1.4426950408889634f, scale);
+  if (ld > 0)
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, true>), head_grid((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out, lse,
+                       B, H, N, dh, ld, scale * 1.4426950408889634f, scale);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, false>), head_grid((N + 127) / 128, B * H), dim3(256), smem, s, q, k, v, out,
+                       lse, B, H, N, dh, 0, scale * 1.4426950408889634f, scale);
   return hipGetLastError();
 }
 
@@ -712,11 +731,20 @@ static hipError_t bwd_launch(const bf16* q, const bf16* k, const bf16* v, const 
   constexpr int smem_kv = 3 * (2 * ((32 * (C::DSTR / 16) + 63) / 64) * 1024 + 32 * 8);
   constexpr int smem_q = 3 * (((32 * (C::DSTR / 16) + 63) / 64) + ((32 * (C::RSTR / 16) + 63) / 64)) * 1024;
   const dim3 grid = head_grid((N + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attn_bwd_q_kernel<DP>, grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N, dh, ld, c,
-                     scale);
+  if (ld > 0)
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DP, true>), grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N,
+                       dh, ld, c, scale);
+  else
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DP, false>), grid, block, smem_q, s, q, k, v, out, dout, lse, delta, dqkv, B, H, N,
+                       dh, 0, c, scale);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<DP>, grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, ld, c, scale);
+  if (ld > 0)
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DP, true>), grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, ld, c,
+                       scale);
+  else
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DP, false>), grid, block, smem_kv, s, q, k, v, dout, delta, dqkv, B, H, N, dh, 0,
+                       c, scale);
   return hipGetLastError();
 }
 
@@ -734,6 +762,8 @@ hipError_t attn_fwd(const void* q, const void* k, const void* v, int dtype, void
   if (B * H == 0 || N == 0) return hipSuccess;
   if (dtype == DT_F32)
     return attn_ref_fwd((const float*)q, (const float*)k, (const float*)v, (float*)out, lse, B, H, N, dh, DP, ld, s);
+  if (dtype == DT_F32_MFMA)
+    return attn_f32_fwd((const float*)q, (const float*)k, (const float*)v, (float*)out, lse, B, H, N, dh, DP, ld, s);
   if (!attn_shape_ok(N, dh, DP, H, ld)) return hipErrorInvalidValue;
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return hipErrorInvalidValue;
 #define SGL_F(DPV) \
@@ -751,6 +781,9 @@ hipError_t attn_bwd(const void* q, const void* k, const void* v, const void* out
   if (B * H == 0 || N == 0) return hipSuccess;
   if (dtype == DT_F32)
     return attn_ref_bwd((const float*)q, (const float*)k, (const float*)v, (const float*)out, (const float*)dout, lse,
+                        (float*)dqkv, delta, B, H, N, dh, DP, ld, s);
+  if (dtype == DT_F32_MFMA)
+    return attn_f32_bwd((const float*)q, (const float*)k, (const float*)v, (const float*)out, (const float*)dout, lse,
                         (float*)dqkv, delta, B, H, N, dh, DP, ld, s);
   if (!attn_shape_ok(N, dh, DP, H, ld)) return hipErrorInvalidValue;
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return hipErrorInvalidValue;

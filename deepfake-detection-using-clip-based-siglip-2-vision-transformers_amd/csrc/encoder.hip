@@ -547,8 +547,8 @@ int sgl_forward_slots(sgl_ctx* ctx, const sgl_weights* w, const void* shadow, co
     {
       const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
       char* q = lb + lay.r_qkv;
-      CK(attn_fwd(q, q + hsz, q + 2 * hsz, dt, lb + lay.r_attn, reinterpret_cast<float*>(lb + lay.r_lse), B, Hh, N, dh,
-                  DP, 0, s));
+      CK(attn_fwd(q, q + hsz, q + 2 * hsz, ctx->split ? DT_F32_MFMA : dt, lb + lay.r_attn,
+                  reinterpret_cast<float*>(lb + lay.r_lse), B, Hh, N, dh, DP, 0, s));
     }
     {
       EpiParams p;
@@ -904,8 +904,9 @@ int sgl_backward_layer_p(sgl_ctx* ctx, const sgl_weights* w, const void* shadow,
   {
     const size_t hsz = (size_t)B * Hh * N * DP * ctx->es;
     const char* q = lb + lay.r_qkv;
-    CK(attn_bwd(q, q + hsz, q + 2 * hsz, lb + lay.r_attn, dhb, reinterpret_cast<const float*>(lb + lay.r_lse), dt, dqkv,
-                reinterpret_cast<float*>(at(ws, lay.w_delta)), nullptr, B, Hh, N, dh, DP, 0, s));
+    CK(attn_bwd(q, q + hsz, q + 2 * hsz, lb + lay.r_attn, dhb, reinterpret_cast<const float*>(lb + lay.r_lse),
+                ctx->split ? DT_F32_MFMA : dt, dqkv, reinterpret_cast<float*>(at(ws, lay.w_delta)), nullptr, B, Hh, N, dh,
+                DP, 0, s));
   }
   {
     float* gw[3] = {lg.q_w, lg.k_w, lg.v_w};

@@ -177,6 +177,9 @@ __device__ __forceinline__ void store_tile256(char* smem, f32x4 (&acc)[8][4], in
           if (p.out) Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out) + (size_t)grow * p.ldo + gcol, v);
           Vec<TOut, NV>::st_nt(reinterpret_cast<TOut*>(p.out2) + (size_t)grow * p.ldo2 + gcol, a);
         } else if constexpr (EPI == EPI_QKV) {
+          // (Round 3 tried dealing a pass's chunks out head by head so that a wave store covers 6.4 whole 160-byte rows of
+          // one head, 1 KiB contiguous instead of eight 144-byte pieces: QKV GEMM 853 -> 886 us, the per-chunk decode costs
+          // more than the store pattern saves.  Not kept.)
           // row / tokens without the ~35-instruction integer division: float reciprocal estimate + one exact correction
           int b = (int)((float)grow * __builtin_amdgcn_rcpf((float)p.tokens));
           int n = grow - b * p.tokens;

@@ -7,7 +7,7 @@
 
 namespace sgl {
 
-enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F32_MFMA = 2 /* attention only: fp32 operands on v_mfma_f32_32x32x2_f32 */ };
 static inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
 // ---- GEMM epilogues (shared by the MFMA kernels and the strict-fp32 generic kernel) ----------------

@@ -147,17 +147,27 @@ def _hip_colsum(lib, _lib, t, M, N, stream):
     return out
 
 
-_HIP_LINEAR = __import__("os").environ.get("SGL_HEADS_LINEAR", "hip") != "torch"   # developer A/B switch
+# developer A/B switch: "hip" (default) every token-major Linear / 1x1 convolution of the decoder under bf16 autocast runs on
+# this repo's MFMA GEMMs (256x256-tile kernels for large shapes, the 128x128-tile kernels for narrow ones: E = 256
+# projections, the gate's bottleneck, the 1-channel head); "wide": only shapes with >= 512 columns (round 2's rule, the
+# rest on the vendor GEMM behind F.linear); "torch": F.linear everywhere
+_HIP_LINEAR = __import__("os").environ.get("SGL_HEADS_LINEAR", "hip")
 
 
 def _linear_tokens(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
-    """F.linear on (..., K) token-major data; under CUDA autocast with MFMA-friendly sizes it runs on the HIP GEMMs."""
+    """F.linear on (..., K) token-major data; under CUDA bf16 autocast it runs on the HIP GEMMs (bf16 operands, fp32
+    accumulate: the arithmetic autocast's F.linear does).  fp32 callers (strict parity runs, CPU) keep F.linear."""
     K, N = x.shape[-1], weight.shape[0]
-    if (_HIP_LINEAR and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
-            and K % 8 == 0 and N % 8 == 0 and N >= 512 and K >= 512 and x.numel() // K >= 2048):
-        # 256x256-tile kernels: worth it from 512 output columns (measured: E=512 decoder -5 %, E=256 decoder +5 % slower)
-        y = _hip_linear(x.reshape(-1, K), weight, bias)
-        return y.reshape(*x.shape[:-1], N)
+    if (_HIP_LINEAR != "torch" and x.is_cuda and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and K % 8 == 0 and x.numel() // K >= 64):
+        wide = N % 8 == 0 and N >= 512 and K >= 512 and x.numel() // K >= 2048
+        if wide or _HIP_LINEAR == "hip":
+            if N % 8:   # the 1-channel mask head: pad the output columns to the GEMM's 8-column granularity
+                pad = 8 - N % 8
+                weight = F.pad(weight, (0, 0, 0, pad))
+                bias = None if bias is None else F.pad(bias, (0, pad))
+            y = _hip_linear(x.reshape(-1, K), weight, bias)
+            return y.reshape(*x.shape[:-1], y.shape[-1])[..., :N]
     return F.linear(x, weight, bias)
 
 

@@ -142,6 +142,7 @@ def load():
     _sig(lib, "sgl_op_dwconv3x3_wgrad_scratch_bytes", sz, [i, i, i, i])
     _sig(lib, "sgl_op_dwconv3x3_wgrad", i, [_fp, _fp, i, _fp, i, _fp, sz, i, i, i, i, _fp])
     _sig(lib, "sgl_op_preprocess", i, [_fp, i, i, i, i, _fp, i, i, i, i, i, f, f, _fp, f, _fp])
+    _sig(lib, "sgl_op_preprocess_aug", i, [_fp, i, i, i, i, _fp, i, i, i, i, i, f, f, _fp, _fp, _fp])
     _sig(lib, "sgl_op_l2norm_tmean_fwd", i, [_fp, _fp, _fp, i, i, i, _fp])
     _sig(lib, "sgl_op_l2norm_tmean_bwd", i, [_fp, _fp, _fp, _fp, i, i, i, _fp])
     _sig(lib, "sgl_op_gate_mul", i, [_fp, _fp, _fp, sz, i, _fp])

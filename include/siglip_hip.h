@@ -204,6 +204,8 @@ int sgl_op_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, in
 int sgl_op_gemm_tn_ws(int dtype, const void* A, int lda, const void* B, int ldb, int Mred, int N1, int N2, int splits,
                       float* out, int ldo, int accumulate, float* scratch, size_t scratch_bytes, sgl_stream stream);
 /* Scaled-dot-product attention of one block (TF:modeling_siglip.py:227-247,288-301), all heads and images in one launch.
+ * dtype: SGL_DTYPE_BF16 (bf16 operands, bf16 MFMA, fp32 softmax), SGL_DTYPE_F32 (fp32 operands, plain FMAs: the reference
+ *   kernels) or SGL_DTYPE_BF16X3 (fp32 operands on v_mfma_f32_32x32x2_f32: what the strict MFMA mode uses).
  * ld_qkv > 0 (what the encoder uses since ABI 3): q, k, v point at the three column blocks of the QKV projection's
  *   token-major output [B*N][ld_qkv]; head h of token row r is the head_dim elements at r*ld_qkv + h*head_dim (16-byte
  *   aligned: head_dim % 8 == 0, ld_qkv % 8 == 0, pointers 16-byte aligned).  Nothing is padded in memory.
@@ -250,6 +252,24 @@ int sgl_op_dwconv3x3_wgrad(const void* x, const void* dy, int dtype, float* dw10
 int sgl_op_preprocess(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws, void* out, int out_dtype, int S, int P,
                       int Kp, int patch_major, float mean, float std, const int* mix_index, float lam,
                       sgl_stream stream);
+
+/* Augmentation branch of the video trainer's GPU transform (hidf_video_classifier.py:2868-2874): K.Resize(S, antialias) ->
+ * RandomHorizontalFlip -> RandomRotation(+-5 deg, bilinear, zeros outside) -> ColorJitter -> K.Normalize, one pass, same
+ * sources / outputs as sgl_op_preprocess.  Random draws stay with the caller: aug is a DEVICE table of B samples.
+ *   flip != 0: mirror x.  (cos_a, sin_a): rotation about the image centre, counter-clockwise positive; (1, 0) = none.
+ *   order[]: permutation of {0 brightness (x*f), 1 contrast ((x-m)*f+m, m = mean grey level of the image at that point),
+ *   2 saturation ((x-grey)*f+grey), 3 hue (h += hue, fraction of the circle)}, each result clamped to [0,1];
+ *   order[0] < 0 = no colour jitter for this sample.  grey_mean: device scratch of B floats.
+ * kornia itself is not installed in the build image: parity with it is unpinned; oracle/preprocess_oracle.py restates
+ * exactly the operators above (torchvision's definitions). */
+typedef struct sgl_aug_sample {
+  float flip, cos_a, sin_a, brightness, contrast, saturation, hue;
+  int order[4];
+  int reserved;
+} sgl_aug_sample;
+int sgl_op_preprocess_aug(const void* src, int src_is_u8_nhwc, int B, int Hs, int Ws, void* out, int out_dtype, int S,
+                          int P, int Kp, int patch_major, float mean, float std, const sgl_aug_sample* aug,
+                          float* grey_mean, sgl_stream stream);
 
 /* Video tail (hidf_video_classifier.py:304-316): per-frame embeddings f (B*T, D) fp32 -> each frame L2-normalised ->
  * mean over the T frames of a clip -> out (B, D); inv_norm (B*T) keeps 1/|f_t| for the backward

@@ -30,8 +30,9 @@ def test_forward_backward_vs_hf_golden(case, mode, pkg, oracle, hiplib):
     x = pkg.weights.seeded_pixels(m["batch"], m["res"], m["res"], seed=m["seed"] + 1000).cuda()
     out = model(pixel_values=x, output_hidden_states=True, interpolate_pos_encoding=m["interp"])
     strict = mode in ("fp32", "bf16x3")
-    # bf16x3 (strict mode on the matrix cores: split-bf16 GEMMs, ~2^-17 per product) gets X3 times the fp32 mode's bounds
-    X3 = 16.0 if mode == "bf16x3" else 1.0
+    # bf16x3 (strict mode on the matrix cores: split-bf16 GEMMs, ~2^-17 per product, fp32-MFMA attention) gets X3 times the
+    # fp32 mode's bounds: measured on MI355X 2.0e-5 .. 5.0e-5 abs on activations against 6.2e-6 for plain fp32
+    X3 = 6.0 if mode == "bf16x3" else 1.0
 
     def tol(prefix):
         """fp32: fixed (2x the measured 6.2e-6 / 1.4e-6 relative); bf16: 3x what HF under bf16 autocast does on this tensor."""

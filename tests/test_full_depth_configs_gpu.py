@@ -132,11 +132,15 @@ def test_config4_sid_multitask_full_27_blocks_384(pkg, hiplib, so400m_graph):
           + f"; decoder proj {gd:.2e} fuse {gf:.2e} cls {gc:.2e}")
     assert named["encoder.layers.20.mlp.fc1.weight"].grad is None
     assert named["embeddings.patch_embedding.weight"].grad is None
-    # bounds = 2x the values measured on MI355X in round 3 (printed above)
-    assert e_cls <= 4e-2
-    assert seg_l2 <= 3e-2
-    assert abs(loss.item() - loss_ref.item()) <= 6e-3 * abs(loss_ref.item())
-    assert max(ge.values()) <= 5e-2 and gd <= 3e-2 and gf <= 3e-2 and gc <= 3e-2
+    # bounds = 2x the values measured on MI355X in round 3 (printed above): cls 5.9e-3 abs, seg 3.2e-3 rel-L2, loss 4e-4
+    # relative, gradients 8.6e-3 .. 9.3e-3 (decoder 5.1e-3 .. 8.4e-3) and 5.6e-2 for the last block's query projection (the
+    # ill-conditioned tensor explained at CFG3_TOL)
+    assert e_cls <= 1.2e-2
+    assert seg_l2 <= 6.4e-3
+    assert abs(loss.item() - loss_ref.item()) <= 1e-3 * abs(loss_ref.item())
+    for k, v in ge.items():
+        assert v <= (1.2e-1 if "q_proj" in k else 1.9e-2), (k, v)
+    assert gd <= 1.6e-2 and gf <= 1.1e-2 and gc <= 1.7e-2
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

@@ -207,7 +207,7 @@ def attn_reference(q, k, v, dout):
 
 @pytest.mark.parametrize("B,H,N,dh", [(1, 2, 4, 16), (2, 2, 9, 72), (2, 4, 49, 16), (1, 3, 196, 64), (2, 16, 729, 72),
                                       (1, 2, 1024, 72), (1, 2, 130, 32)])
-@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("dtype", [BF16, F32, 2])   # 2 = SGL_DTYPE_BF16X3: fp32 operands on the fp32 MFMA (attention_f32.hip)
 @pytest.mark.parametrize("layout", ["token", "head"])
 def test_attention_fwd_bwd(lib, B, H, N, dh, dtype, layout):
     """layout "token": q | k | v are the column blocks of one token-major [B*N, 3D] matrix (what the encoder's QKV GEMM

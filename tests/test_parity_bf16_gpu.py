@@ -125,7 +125,7 @@ def full_depth_reference(pkg, oracle):
 # bf16x3 = strict mode on the matrix cores (split-bf16 GEMMs; attention in fp32): its bound is the north-star one, pooled
 # output within 1e-3 abs of the fp32 reference, plus 2x what round 3 measured for the other tensors.
 FULL_TOL = {"fp32": dict(act=3e-6, grad=1.4e-5, pooled_abs=2e-5, loss=2e-6),
-            "bf16x3": dict(act=1e-4, grad=4e-4, pooled_abs=1e-3, loss=1e-4),
+            "bf16x3": dict(act=2e-5, grad=3.6e-5, pooled_abs=8e-5, loss=2e-5),   # measured 9.7e-6 / 1.8e-5 / 4.0e-5
             "bf16": dict(act=1.1e-2, grad=2.1e-2, pooled_abs=4.4e-2, loss=8e-3)}
 
 

@@ -79,3 +79,72 @@ def test_patch_operand_feeds_the_encoder(pkg, hiplib, po, cfg_name, hs, ws):
             (o.pooler_output.square().mean() + o.last_hidden_state.mean()).backward()
             outs.append((o.pooler_output.detach().clone(), model.embeddings.patch_embedding.weight.grad.clone()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def _aug_params():
+    import math
+    a1, a2 = math.radians(4.0), math.radians(-5.0)
+    return [
+        dict(flip=False, cos=1.0, sin=0.0, brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, order=None),  # identity
+        dict(flip=True, cos=math.cos(a1), sin=math.sin(a1), brightness=1.07, contrast=0.93, saturation=1.09, hue=0.04,
+             order=[2, 0, 3, 1]),
+        dict(flip=False, cos=math.cos(a2), sin=math.sin(a2), brightness=0.91, contrast=1.1, saturation=0.9, hue=-0.05,
+             order=[1, 3, 0, 2]),
+        dict(flip=True, cos=1.0, sin=0.0, brightness=1.1, contrast=1.05, saturation=1.0, hue=0.0, order=[0, 1, 2, 3]),
+    ]
+
+
+def test_oracle_colour_operators_are_identities_at_neutral_parameters(po):
+    """The restated operators at their neutral parameters (factor 1, hue 0, angle 0) reproduce the plain transform; a pure
+    90-degree-free sanity check of the HSV round trip and of the rotation sampler."""
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(2, 3, 40, 40, generator=g)
+    neutral = [dict(flip=False, cos=1.0, sin=0.0, brightness=1.0, contrast=1.0, saturation=1.0, hue=0.0, order=[3, 1, 0, 2])] * 2
+    assert (po.augment_transform(img, 40, neutral) - po.gpu_transform(img, 40)).abs().max().item() < 2e-6
+    x = torch.rand(3, 17, 17, generator=g)
+    assert torch.equal(po.rotate_bilinear_zeros(x, 1.0, 0.0), x)
+    # a quarter turn maps pixels exactly (no interpolation): out(y, x) = in(x, S-1-y) for the counter-clockwise convention
+    r = po.rotate_bilinear_zeros(x, 0.0, 1.0)
+    assert (r - x.transpose(-1, -2).flip(-2)).abs().max().item() < 1e-5 or \
+        (r - x.transpose(-1, -2).flip(-1)).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", ["u8", "f32"])
+@pytest.mark.parametrize("hs,ws,size", [(96, 120, 56), (56, 56, 56), (40, 70, 42)])
+def test_augmentation_branch_matches_oracle(pkg, hiplib, po, src, hs, ws, size):
+    """Resize -> flip -> rotation(+-5 deg) -> colour jitter (all four operators, three different orders) -> normalize, fused
+    (csrc/preprocess.hip), against the explicit restatement in oracle/preprocess_oracle.py; kornia itself: parity unpinned."""
+    g = torch.Generator().manual_seed(hs + ws)
+    if src == "u8":
+        img = torch.randint(0, 256, (4, hs, ws, 3), generator=g, dtype=torch.uint8)
+    else:
+        img = torch.rand(4, 3, hs, ws, generator=g)
+    params = _aug_params()
+    ref = po.augment_transform(img, size, params)
+    got = pkg.preprocess.augment_resize_normalize(img.cuda(), size, params)
+    err = (got.cpu() - ref).abs()
+    # hue: a pixel whose two largest channels tie within rounding may pick the other branch of the piecewise HSV formula on
+    # either side; both are correct to rounding but differ by O(1e-3) for that pixel — allow a handful
+    assert (err > 2e-5).float().mean().item() < 1e-4, err.max().item()
+    assert err.max().item() < 5e-3
+    assert torch.equal(got[0], pkg.preprocess.resize_normalize(img.cuda(), size)[0])     # identity record == plain transform
+
+
+@pytest.mark.gpu
+def test_augmented_patch_operand_and_module(pkg, hiplib, po):
+    cfg = pkg.get_config("hostile")
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (4, 60, 75, 3), generator=g, dtype=torch.uint8)
+    params = _aug_params()
+    S, P = cfg.image_size, cfg.patch_size
+    px = pkg.preprocess.augment_resize_normalize(img.cuda(), S, params)
+    op = pkg.preprocess.augment_to_patch_operand(img.cuda(), cfg, params, compute_dtype="fp32")
+    assert torch.equal(op.data.cpu(), po.patch_operand(px.cpu(), P))                       # same pixels, operand layout
+    opb = pkg.preprocess.augment_to_patch_operand(img.cuda(), cfg, params, compute_dtype="bf16")
+    assert torch.equal(opb.data.float().cpu(), po.patch_operand(px.cpu(), P).bfloat16().float())
+    gen = torch.Generator().manual_seed(3)
+    mod = pkg.preprocess.GpuTransform(S, data_augmentation=True, generator=gen).cuda().train()
+    want = pkg.preprocess.sample_augmentation(4, torch.Generator().manual_seed(3))
+    assert torch.equal(mod(img.cuda()), pkg.preprocess.augment_resize_normalize(img.cuda(), S, want))
+    assert torch.equal(mod.eval()(img.cuda()), pkg.preprocess.resize_normalize(img.cuda(), S))   # eval: no augmentation
