@@ -360,7 +360,10 @@ hipError_t gemm_nt_bf16(const void* A_, int lda, const void* B_, int ldb, int M,
   if ((lda % 8) || (ldb % 8) || (K % 8) || K <= 0) return hipErrorInvalidValue;
   if (epi != EPI_F32 && (N % 8)) return hipErrorInvalidValue;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return hipErrorInvalidValue;
-  if (gemm_generation() != 1 && M >= 2048 && N >= 256) {
+#ifndef SGL_NT6_MIN_N
+#define SGL_NT6_MIN_N 256
+#endif
+  if (gemm_generation() != 1 && M >= 2048 && N >= SGL_NT6_MIN_N) {
 #ifdef SGL_AB
     // generation 7 (persistent tile loop, gemm_bf16_v3.hip): measured equal-or-slower than generation 6 on the encoder's
     // shapes (negative results); A/B build only: SGL_GEMM_GEN=7

@@ -441,7 +441,7 @@ __device__ __forceinline__ u32x4 pp_desc(const void* base, uint32_t bytes) {
 // G0 runs R1 in slot 4t, G1 in slot 4t+1.
 // Developer build (make TIMELINE=1, then SGL_TIMELINE=1 in the environment): s_memtime stamps at kernel entry, end of the
 // main loop and end of the epilogue, summed over all workgroups and printed per launch.  This is the tool behind the
-// epilogue findings of DESIGN.md section 8c (loads queued behind stores; fc1's main loop slowed by its own output traffic).
+// epilogue findings of DESIGN.md section 8.4, round 2 (loads queued behind stores; fc1's main loop slowed by its own output traffic).
 #ifdef SGL_TIMELINE
 __device__ unsigned long long g_nt6_tl[4];
 #define SGL_TL_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()

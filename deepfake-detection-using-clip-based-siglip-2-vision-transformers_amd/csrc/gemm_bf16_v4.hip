@@ -18,7 +18,7 @@
 // SIMD the 64 DMA instructions of a K-step — 1024 cycles of the CU's texture path (16 cycles each, in-order issue) — stall
 // the very waves that feed the matrix pipe, and they can only be issued in the half of the K-step after the stage is
 // released; generation 6 issues them from the group that is NOT in its MFMA slot; (2) even the DMA-free loop is only 5 %
-// above generation 6: with real operands the chip's clock under matrix load (DESIGN.md section 8c) caps both.  Kept opt-in
+// above generation 6: with real operands the chip's clock under matrix load (DESIGN.md section 8.3) caps both.  Kept opt-in
 // for A/B runs; the four-wave epilogue is also slower (half as many waves do the same store work).
 #include <stdlib.h>
 

@@ -143,14 +143,24 @@ def test_config4_sid_multitask_full_27_blocks_384(pkg, hiplib, so400m_graph):
     assert gd <= 1.6e-2 and gf <= 1.1e-2 and gc <= 1.7e-2
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_config5_video_clip_of_32_frames_through_all_27_blocks(mode, pkg, oracle, hiplib):
-    """BASELINE config 5 at full depth, the script's frozen-backbone default (hidf_video_classifier.py:2913-2916): one clip
-    of 32 frames -> 32 images through all 27 so400m blocks -> L2-norm -> temporal mean -> MLP -> one logit
-    (:299-320), forward only, against oracle o CPU head."""
-    H = pkg.heads
+@pytest.fixture(scope="module")
+def clip_reference(pkg, oracle):
+    """fp32 CPU oracle embeddings of one seeded 32-frame clip (computed once for both compute modes)."""
     cfg = pkg.get_config("so400m-patch14-384")
     sd = pkg.weights.seeded_state_dict(cfg, seed=41)
+    clip = pkg.weights.seeded_pixels(32, 384, 384, seed=42).view(1, 32, 3, 384, 384)
+    with torch.no_grad():
+        ref = oracle.vision_forward(clip.view(32, 3, 384, 384), sd, cfg, False, False)["pooler_output"]
+    return cfg, sd, clip, ref
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_config5_video_clip_of_32_frames_through_all_27_blocks(mode, pkg, hiplib, clip_reference):
+    """BASELINE config 5 at full depth, the script's frozen-backbone default (hidf_video_classifier.py:2913-2916): one clip
+    of 32 frames -> 32 images through all 27 so400m blocks -> L2-norm -> temporal mean -> MLP -> one logit
+    (:299-320), forward only, against oracle o CPU head; strict mode = the one that runs on the matrix cores."""
+    H = pkg.heads
+    cfg, sd, clip, ref_pooled = clip_reference
     enc = pkg.OpenClipStyleEncoder(cfg, mode)
     enc.visual.load_state_dict(sd)
     torch.manual_seed(5)
@@ -159,19 +169,17 @@ def test_config5_video_clip_of_32_frames_through_all_27_blocks(mode, pkg, oracle
     vid = vid.cuda()
     for p in vid.vision_encoder.parameters():
         p.requires_grad = False
-    clip = pkg.weights.seeded_pixels(32, 384, 384, seed=42).view(1, 32, 3, 384, 384)
     with torch.no_grad():
         logit = vid(clip.cuda())
         feats = enc.encode_image(clip.view(32, 3, 384, 384).cuda())
-        ref = oracle.vision_forward(clip.view(32, 3, 384, 384), sd, cfg, False, False)
-        ref_logit = head_cpu(ref["pooler_output"], batch_size=1)
+        ref_logit = head_cpu(ref_pooled, batch_size=1)
     assert logit.shape == (1,)
     err = (logit.cpu() - ref_logit).abs().max().item()
-    ferr = rel_l2(feats, ref["pooler_output"])
+    ferr = rel_l2(feats, ref_pooled)
     print(f"[config 5 full depth {mode}] clip logit {logit.item():.6f} vs {ref_logit.item():.6f} (|err| {err:.2e}); "
           f"frame embeddings rel-L2 {ferr:.2e}")
     # bounds = 2x measured (round 3)
-    if mode == "fp32":
-        assert err <= 2e-5 and ferr <= 1e-5
+    if mode == "bf16x3":
+        assert err <= 1e-4 and ferr <= 4e-5
     else:
         assert err <= 1e-2 and ferr <= 2e-2

@@ -363,14 +363,18 @@ def test_gemm_tn_with_scratch_is_reproducible_and_correct(lib):
     assert relerr(acc, 2 * outs[0]) < 1e-6
 
 
-@pytest.mark.parametrize("gen", ["7", "8"])
+@pytest.mark.parametrize("gen", ["2", "7", "8"])
 def test_opt_in_nt_gemm_generations_are_correct(gen):
-    """The opt-in NT GEMM generations (SGL_GEMM_GEN=7 persistent, =8 four-wave; DESIGN.md negative results) stay correct on
-    the encoder's eight shapes: tests/bench_nt.py checks every launch against torch (head, tail rows, pad columns) and
-    asserts.  The generation is latched per process, hence the subprocess."""
+    """The A/B NT GEMM generations (SGL_GEMM_GEN=2 one barrier per K-step, =7 persistent, =8 four-wave; DESIGN.md negative
+    results) live only in the developer library libsiglip_hip_ab.so (make AB=1; __graft_entry__.build() builds it) and stay
+    correct on the encoder's eight shapes: tests/bench_nt.py checks every launch against torch (head, tail rows, pad
+    columns) and asserts.  The generation is latched per process, hence the subprocess."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SGL_GEMM_GEN=gen)
+    ab = os.path.join(root, "deepfake-detection-using-clip-based-siglip-2-vision-transformers_amd", "libsiglip_hip_ab.so")
+    if not os.path.exists(ab):
+        pytest.skip("developer A/B library not built (make -C csrc AB=1)")
+    env = dict(os.environ, SGL_GEMM_GEN=gen, SGL_LIB_PATH=ab)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "bench_nt.py"), "8"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
