@@ -444,6 +444,7 @@ __device__ __forceinline__ u32x4 pp_desc(const void* base, uint32_t bytes) {
 // epilogue findings of DESIGN.md section 8.4, round 2 (loads queued behind stores; fc1's main loop slowed by its own output traffic).
 #ifdef SGL_TIMELINE
 __device__ unsigned long long g_nt6_tl[4];
+__device__ unsigned long long g_tn6_tl[12];   // [group][phase 0..4, slot-pair count]
 #define SGL_TL_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
 #else
 #define SGL_TL_STAMP(v)
@@ -659,19 +660,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn6_kernel(const bf16* __restrict
 
 #define SGL_TR6(ptr) __builtin_shufflevector(lds_tr16v2(ptr), lds_tr16v2((ptr) + 4 * 512), 0, 1, 2, 3, 4, 5, 6, 7)
   bf16x8 fa[8], fb[4];
+#ifdef SGL_TIMELINE
+  // per-phase cycle sums of this wave over the main loop: [0] issue fragment reads + DMA, [1] wait for them (lgkmcnt/vmcnt),
+  // [2] barrier after the read slot, [3] 32 MFMAs, [4] barrier after the MFMA slot
+  unsigned long long tlp[5] = {0, 0, 0, 0, 0};
+#define SGL_TLP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); tlp[i] += n_ - tl_last; tl_last = n_; } while (0)
+  unsigned long long tl_last = __builtin_readcyclecounter();
+#else
+#define SGL_TLP(i)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = smem + (kt & 1) * T_STAGE + frow;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (active) {
+#if !defined(SGL_TN_ABLATE) || SGL_TN_ABLATE != 1
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = SGL_TR6(base + T_OP + h * 32 * 512 + (fb_col ^ (uint32_t)(j * 32)));
+#else
+        if (kt == 0)   // ablation (wrong results): B fragments read once -> read slots carry A only
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[j] = SGL_TR6(base + T_OP + h * 32 * 512 + (fb_col ^ (uint32_t)(j * 32)));
+#endif
+#if !defined(SGL_TN_ABLATE) || SGL_TN_ABLATE != 2
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] = SGL_TR6(base + h * 32 * 512 + (fa_col ^ (uint32_t)(i * 32)));
+#else
+        if (kt == 0)   // ablation (wrong results): A fragments read once -> read slots carry B only
+#pragma unroll
+          for (int i = 0; i < 8; ++i) fa[i] = SGL_TR6(base + h * 32 * 512 + (fa_col ^ (uint32_t)(i * 32)));
+#endif
       }
       if (h == 0) { issue(2, kt + 1); issue(3, kt + 1); }
       else { issue(0, kt + 2); issue(1, kt + 2); }
+#ifdef SGL_TIMELINE
+      SGL_TLP(0);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      SGL_TLP(1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      SGL_TLP(2);
+#else
       SGL_PP_END_READ8();
+#endif
       if (active) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -681,9 +713,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn6_kernel(const bf16* __restrict
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
+#ifdef SGL_TIMELINE
+      asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[7][3]));
+      SGL_TLP(3);
+#endif
       SGL_PP_END_MFMA();
+      SGL_TLP(4);
     }
   }
+#ifdef SGL_TIMELINE
+  if (lane == 0 && active && (w == 0 || w == 4)) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_tn6_tl[(w >> 2) * 6 + i], tlp[i]);
+    atomicAdd(&g_tn6_tl[(w >> 2) * 6 + 5], (unsigned long long)(2 * nk));
+  }
+#endif
 #undef SGL_TR6
   if (grp == 0) SGL_PP_END_MFMA();   // G0 waits for G1's last slot
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) units must land before the LDS is reused
@@ -903,6 +946,21 @@ hipError_t gemm_tn2_bf16(const void* A_, int lda, const void* B_, int ldb, int M
   }
   hipLaunchKernelGGL(gemm_tn6_kernel, dim3(grid), dim3(512), T_LDS, s, (const bf16*)A_, lda, (const bf16*)B_, ldb,
                      Mred, N1, N2, m_per, splits, tiles_1, tiles_2, p);
+#ifdef SGL_TIMELINE
+  if (getenv("SGL_TIMELINE")) {   // synchronises: measurement builds only
+    unsigned long long h[12];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tn6_tl), sizeof(h));
+    for (int g = 0; g < 2; ++g)
+      if (h[g * 6 + 5])
+        fprintf(stderr, "[timeline] gemm_tn6 N1=%d N2=%d Mred=%d splits=%d group %d, cycles per slot pair (read slot + MFMA slot): issue "
+                "reads+DMA %.0f, wait %.0f, barrier %.0f, 32 MFMAs %.0f, barrier %.0f\n", N1, N2, Mred, splits, g,
+                (double)h[g * 6 + 0] / h[g * 6 + 5], (double)h[g * 6 + 1] / h[g * 6 + 5], (double)h[g * 6 + 2] / h[g * 6 + 5],
+                (double)h[g * 6 + 3] / h[g * 6 + 5], (double)h[g * 6 + 4] / h[g * 6 + 5]);
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn6_tl), h, sizeof(h));
+  }
+#endif
   return hipGetLastError();
 }
 
