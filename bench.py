@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--freeze-below", type=int, default=0,
                     help="secondary metric (SURVEY.md 8d): freeze embeddings and blocks < K as Siglip2sidafrozen.py:757-768")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--kernel-reps", type=int, default=20,
                     help="launches per kernel for the roofline / breakdown legs; 0 skips them (clean rocprofv3 traces)")
     ap.add_argument("--no-optimizer", action="store_true",

@@ -6,7 +6,7 @@ import __graft_entry__ as g
 pkg = g.load_package(); lib = pkg.lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-H, N, dh, DP = 16, 729, 72, 80
+H, N, dh, DP = (16, 729, 72, 80) if os.environ.get("ATT_SHAPE", "so400m") == "so400m" else (12, 196, 64, 64)
 D = H * dh
 st = torch.cuda.current_stream()
 LAYOUT = os.environ.get("ATT_LAYOUT", "token")   # token: [B*N, 3D] as the encoder's QKV GEMM writes it; head: [3,B,H,N,DP]
