@@ -196,6 +196,123 @@ hipError_t cast_transpose_pad(const float* src, int R, int C, int ld, void* dst,
   return hipGetLastError();
 }
 
+// ---- all weight shadows of one transformer block (or of the pooling head) in ONE launch -----------------------------------
+// The per-step refresh of the compute-dtype weight copies (what autocast re-does every step in the reference,
+// Siglip2sidafrozen.py:1375) used to be 13 launches per block (cast_pad + cast_transpose_pad per matrix, copy_f32 per bias):
+// 350 launches of 5-7 us per so400m step, 153 per base-224 step.  Here a block's matrices are walked in 64x64 tiles of their
+// PADDED destination (zeros outside the source), each tile read once as fp32 and written twice: row-major and, through an LDS
+// transpose, column-major, both with >= 128-byte row segments; one extra workgroup copies / pads the bias vectors.
+template <typename T> __device__ __forceinline__ T cj_cvt(float x);
+template <> __device__ __forceinline__ float cj_cvt<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 cj_cvt<bf16>(float x) { return (bf16)x; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_job_kernel(CastJob job) {
+  __shared__ float lds_raw[64 * 66];
+  T* lt = reinterpret_cast<T*>(lds_raw);
+  const int t = threadIdx.x;
+  int tile = blockIdx.x;
+  if (tile >= job.ntiles) {   // the vectors: dst[i] = i < n ? src[i] : 0 for i < np  (fp32)
+    for (int v = 0; v < job.nvec; ++v)
+      for (int i = t; i < job.vnp[v]; i += 256) job.vdst[v][i] = (i < job.vn[v]) ? job.vsrc[v][i] : 0.f;
+    return;
+  }
+  int mi = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) mi += (k < job.nmat && tile >= job.m[k].tile0) ? 1 : 0;
+  CastMat m = job.m[0];
+#pragma unroll
+  for (int k = 1; k < 6; ++k)
+    if (mi == k) m = job.m[k];
+  tile -= m.tile0;
+  const int tr = tile / m.tiles_c, tc = tile - tr * m.tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = t & 15, ty = t >> 4;
+  T* dst = reinterpret_cast<T*>(m.dst);
+  const bool vsrc_ok = ((m.lds & 3) == 0) && ((((uintptr_t)m.src) & 15) == 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 16 * k, cc = c0 + tx * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < m.R && cc < m.C) {
+      const float* sp = m.src + (size_t)r * m.lds + cc;
+      if (vsrc_ok && cc + 3 < m.C) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sp);
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+      } else {
+        for (int j = 0; j < 4 && cc + j < m.C; ++j) v[j] = sp[j];
+      }
+    }
+    T o4[4] = {cj_cvt<T>(v[0]), cj_cvt<T>(v[1]), cj_cvt<T>(v[2]), cj_cvt<T>(v[3])};
+    if (dst && r < m.Rp && cc < m.Cp) {
+      T* d = dst + (size_t)r * m.ldd + cc;
+      if (cc + 3 < m.Cp && ((((uintptr_t)d) & (4 * sizeof(T) - 1)) == 0)) {
+        if constexpr (sizeof(T) == 2) {
+          u32x2 w;
+          __builtin_memcpy(&w, o4, 8);
+          *reinterpret_cast<u32x2*>(d) = w;
+        } else {
+          u32x4 w;
+          __builtin_memcpy(&w, o4, 16);
+          *reinterpret_cast<u32x4*>(d) = w;
+        }
+      } else {
+        for (int j = 0; j < 4 && cc + j < m.Cp; ++j) d[j] = o4[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lt[(ty + 16 * k) * 66 + tx * 4 + j] = o4[j];
+  }
+  if (!m.dst_t) return;
+  __syncthreads();
+  // transposed copy [Cp][Rp]: output row = source column c0 + oc, 16 consecutive elements = source rows r0 + 16*seg ..
+  T* dt = reinterpret_cast<T*>(m.dst_t);
+  const int oc = t >> 2, seg = t & 3;
+  if (c0 + oc < m.Cp) {
+    const int rb = r0 + seg * 16;
+    T* drow = dt + (size_t)(c0 + oc) * m.ldt + rb;
+    T vals[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vals[j] = lt[(seg * 16 + j) * 66 + oc];
+    if (rb + 15 < m.Rp && ((((uintptr_t)drow) & 15) == 0)) {
+      constexpr int PER = 16 / sizeof(T);
+#pragma unroll
+      for (int q = 0; q < 16 / PER; ++q) {
+        u32x4 w;
+        __builtin_memcpy(&w, &vals[q * PER], 16);
+        *reinterpret_cast<u32x4*>(drow + q * PER) = w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (rb + j < m.Rp) drow[j] = vals[j];
+    }
+  }
+}
+
+void cast_job_add(CastJob& job, const float* src, int R, int C, int lds_, void* dst, int Rp, int Cp, int ldd, void* dst_t,
+                  int ldt) {
+  CastMat& m = job.m[job.nmat++];
+  m.src = src; m.dst = dst; m.dst_t = dst_t;
+  m.R = R; m.C = C; m.lds = lds_; m.Rp = Rp; m.Cp = Cp; m.ldd = ldd; m.ldt = ldt;
+  m.tiles_c = (Cp + 63) / 64;
+  m.tile0 = job.ntiles;
+  job.ntiles += ((Rp + 63) / 64) * m.tiles_c;
+}
+void cast_job_add_vec(CastJob& job, const float* src, int n, float* dst, int np) {
+  job.vsrc[job.nvec] = src; job.vdst[job.nvec] = dst; job.vn[job.nvec] = n; job.vnp[job.nvec] = np;
+  ++job.nvec;
+}
+hipError_t cast_job_run(const CastJob& job, int dst_dtype, hipStream_t s) {
+  if (job.ntiles == 0 && job.nvec == 0) return hipSuccess;
+  const dim3 grid((unsigned)(job.ntiles + (job.nvec ? 1 : 0)));
+  if (dst_dtype == DT_BF16)
+    hipLaunchKernelGGL(cast_job_kernel<bf16>, grid, dim3(256), 0, s, job);
+  else
+    hipLaunchKernelGGL(cast_job_kernel<float>, grid, dim3(256), 0, s, job);
+  return hipGetLastError();
+}
+
 // ---- column sums (bias gradients): two deterministic stages ------------------------------------------
 int colsum_chunks(int M) {
   int c = (M + 511) / 512;

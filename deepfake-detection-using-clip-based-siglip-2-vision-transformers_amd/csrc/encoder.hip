@@ -341,36 +341,35 @@ int sgl_prepare_weights_dirty(sgl_ctx* ctx, const sgl_weights* w, void* shadow, 
   const int D = ctx->D, I = ctx->I, Ip = ctx->Ip, dt = ctx->dt;
   if (globals_dirty)
     CK(cast_pad(w->patch_w, D, ctx->K0, ctx->K0, at(shadow, ctx->sh_wpatch), dt, D, ctx->Kp, ctx->Kp, s));
+  const size_t es = ctx->es;
   for (int l = 0; l < ctx->L; ++l) {
     if (layer_dirty && !layer_dirty[l]) continue;
     const sgl_layer_weights& lw = w->layers[l];
     const ShadowLayer& sl = ctx->sh_layers[l];
     const float* qkv_w[3] = {lw.q_w, lw.k_w, lw.v_w};
     const float* qkv_b[3] = {lw.q_b, lw.k_b, lw.v_b};
+    // one launch per block (elementwise.hip, cast_job_kernel): every matrix read once, written row-major and transposed
+    CastJob job;
     for (int j = 0; j < 3; ++j) {
-      CK(cast_pad(qkv_w[j], D, D, D, at(shadow, sl.wqkv + (size_t)j * D * D * ctx->es), dt, D, D, D, s));
-      CK(cast_transpose_pad(qkv_w[j], D, D, D, at(shadow, sl.wqkv_t + (size_t)j * D * ctx->es), dt, D, D, 3 * D, s));
-      CK(copy_f32(qkv_b[j], reinterpret_cast<float*>(at(shadow, sl.bqkv)) + (size_t)j * D, D, s));
+      cast_job_add(job, qkv_w[j], D, D, D, at(shadow, sl.wqkv + (size_t)j * D * D * es), D, D, D,
+                   at(shadow, sl.wqkv_t + (size_t)j * D * es), 3 * D);
+      cast_job_add_vec(job, qkv_b[j], D, reinterpret_cast<float*>(at(shadow, sl.bqkv)) + (size_t)j * D, D);
     }
-    CK(cast_pad(lw.o_w, D, D, D, at(shadow, sl.wo), dt, D, D, D, s));
-    CK(cast_transpose_pad(lw.o_w, D, D, D, at(shadow, sl.wo_t), dt, D, D, D, s));
-    CK(cast_pad(lw.fc1_w, I, D, D, at(shadow, sl.w1), dt, Ip, D, D, s));
-    CK(cast_transpose_pad(lw.fc1_w, I, D, D, at(shadow, sl.w1_t), dt, D, Ip, Ip, s));
-    CK(cast_pad(lw.fc2_w, D, I, I, at(shadow, sl.w2), dt, D, Ip, Ip, s));
-    CK(cast_transpose_pad(lw.fc2_w, D, I, I, at(shadow, sl.w2_t), dt, Ip, D, D, s));
-    CK(cast_pad(lw.fc1_b, 1, I, I, at(shadow, sl.b1), DT_F32, 1, Ip, Ip, s));
+    cast_job_add(job, lw.o_w, D, D, D, at(shadow, sl.wo), D, D, D, at(shadow, sl.wo_t), D);
+    cast_job_add(job, lw.fc1_w, I, D, D, at(shadow, sl.w1), Ip, D, D, at(shadow, sl.w1_t), Ip);
+    cast_job_add(job, lw.fc2_w, D, I, I, at(shadow, sl.w2), D, Ip, Ip, at(shadow, sl.w2_t), D);
+    cast_job_add_vec(job, lw.fc1_b, I, reinterpret_cast<float*>(at(shadow, sl.b1)), Ip);
+    CK(cast_job_run(job, dt, s));
   }
   if (ctx->cfg.use_head && globals_dirty) {
     const float* kv_w = w->in_proj_w + (size_t)D * D;
-    CK(cast_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv), dt, 2 * D, D, D, s));
-    CK(cast_transpose_pad(kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv_t), dt, D, 2 * D, 2 * D, s));
-    CK(cast_pad(w->out_proj_w, D, D, D, at(shadow, ctx->sh_hwo), dt, D, D, D, s));
-    CK(cast_transpose_pad(w->out_proj_w, D, D, D, at(shadow, ctx->sh_hwo_t), dt, D, D, D, s));
-    CK(cast_pad(w->head_fc1_w, I, D, D, at(shadow, ctx->sh_hw1), dt, Ip, D, D, s));
-    CK(cast_transpose_pad(w->head_fc1_w, I, D, D, at(shadow, ctx->sh_hw1_t), dt, D, Ip, Ip, s));
-    CK(cast_pad(w->head_fc2_w, D, I, I, at(shadow, ctx->sh_hw2), dt, D, Ip, Ip, s));
-    CK(cast_transpose_pad(w->head_fc2_w, D, I, I, at(shadow, ctx->sh_hw2_t), dt, Ip, D, D, s));
-    CK(cast_pad(w->head_fc1_b, 1, I, I, at(shadow, ctx->sh_hb1), DT_F32, 1, Ip, Ip, s));
+    CastJob job;
+    cast_job_add(job, kv_w, 2 * D, D, D, at(shadow, ctx->sh_hwkv), 2 * D, D, D, at(shadow, ctx->sh_hwkv_t), 2 * D);
+    cast_job_add(job, w->out_proj_w, D, D, D, at(shadow, ctx->sh_hwo), D, D, D, at(shadow, ctx->sh_hwo_t), D);
+    cast_job_add(job, w->head_fc1_w, I, D, D, at(shadow, ctx->sh_hw1), Ip, D, D, at(shadow, ctx->sh_hw1_t), Ip);
+    cast_job_add(job, w->head_fc2_w, D, I, I, at(shadow, ctx->sh_hw2), D, Ip, Ip, at(shadow, ctx->sh_hw2_t), D);
+    cast_job_add_vec(job, w->head_fc1_b, I, reinterpret_cast<float*>(at(shadow, ctx->sh_hb1)), Ip);
+    CK(cast_job_run(job, dt, s));
   }
   return SGL_OK;
 }

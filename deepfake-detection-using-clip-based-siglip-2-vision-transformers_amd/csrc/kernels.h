@@ -72,6 +72,25 @@ hipError_t cast_pad(const float* src, int R, int C, int lds_, void* dst, int dst
 // dst[c][r] (row stride ldd) = cast(src[r][c]) for c < Cp, r < Rp, zero outside
 hipError_t cast_transpose_pad(const float* src, int R, int C, int lds_, void* dst, int dst_dtype, int Cp, int Rp,
                               int ldd, hipStream_t s);
+// One launch for all weight shadows of a block: up to 6 matrices (row-major copy [Rp][Cp] with ld ldd and, optionally, the
+// transposed copy [Cp][Rp] with ld ldt, both zero padded outside the R x C source) and up to 4 fp32 vectors (copied, zero padded)
+struct CastMat {
+  const float* src;
+  void* dst;
+  void* dst_t;
+  int R, C, lds, Rp, Cp, ldd, ldt, tiles_c, tile0;
+};
+struct CastJob {
+  CastMat m[6];
+  const float* vsrc[4];
+  float* vdst[4];
+  int vn[4], vnp[4];
+  int nmat = 0, nvec = 0, ntiles = 0;
+};
+void cast_job_add(CastJob& job, const float* src, int R, int C, int lds_, void* dst, int Rp, int Cp, int ldd, void* dst_t,
+                  int ldt);
+void cast_job_add_vec(CastJob& job, const float* src, int n, float* dst, int np);
+hipError_t cast_job_run(const CastJob& job, int dst_dtype, hipStream_t s);
 // bf16x3 operand splits (elementwise.hip): Cs = round_up(C, 8); dst holds 3 * R * Cs bf16
 hipError_t split3_rows(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s);
 hipError_t split3_stack(const float* src, int R, int C, int ld, void* dst, int Cs, int b_side, hipStream_t s);
