@@ -8,7 +8,14 @@
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-template <int MODE>   // 0: 24 x ds_read_b128 per iteration, 1: 48 x ds_read_b64_tr_b16, 2: 48 x ds_read_b64 (plain)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// MODE 0: 24 x ds_read_b128 per iteration, 1: 48 x ds_read_b64_tr_b16, 2: 48 x ds_read_b64 (plain).
+// PARTNER: waves 4-7 (the SIMD partners of waves 0-3) run a saturated v_mfma_f32_16x16x32_bf16 stream instead of reading,
+// as in the anti-phase GEMM slots (4 reading waves next to 4 MFMA waves): bytes per iteration halve, the reported rate is
+// that of the 4 reading waves.
+template <int MODE, bool PARTNER>
 __global__ __launch_bounds__(512) void k(long long* cyc, unsigned* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -29,6 +36,23 @@ __global__ __launch_bounds__(512) void k(long long* cyc, unsigned* out, int iter
   u32x4 acc4 = {0, 0, 0, 0};
   u32x2 acc2 = {0, 0};
   __syncthreads();
+  if (PARTNER && w >= 4) {
+    bf16x8 x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(float)((lane * 7 + i) & 15) * 0.125f; y[i] = (__bf16)(0.5f + 0.01f * i); }
+    f32x4 c[8];
+    for (int i = 0; i < 8; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters * 8; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c[i], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float sacc = 0.f;
+    for (int i = 0; i < 8; ++i) sacc += c[i][0] + c[i][3];
+    out[blockIdx.x * 512 + t] = (unsigned)sacc;
+    if (lane == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
+    return;
+  }
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -73,9 +97,9 @@ int main() {
   const char* names[3] = {"24 x ds_read_b128      ", "48 x ds_read_b64_tr_b16", "48 x ds_read_b64       "};
   for (int mode = 0; mode < 3; ++mode) {
     for (int grid = 1; grid <= 256; grid *= 256) {
-      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
-      if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
-      if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
+      if (mode == 0) hipLaunchKernelGGL((k<0, false>), dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
+      if (mode == 1) hipLaunchKernelGGL((k<1, false>), dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
+      if (mode == 2) hipLaunchKernelGGL((k<2, false>), dim3(grid), dim3(512), 65536, 0, d_cyc, d_out, iters);
       hipDeviceSynchronize();
       long long h[8];
       hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
@@ -85,6 +109,20 @@ int main() {
       printf("%s  8 waves, %3d workgroup(s): %8.1f cycles per 24 KiB/wave iteration = %6.1f B/clk/CU  (a GEMM K-step has 2048 "
              "cycles of MFMA work per SIMD)\n", names[mode], grid, per_iter, 8.0 * 24576.0 / per_iter);
     }
+  }
+  for (int mode = 0; mode < 2; ++mode) {   // 4 reading waves next to 4 MFMA waves (one of each per SIMD)
+    if (mode == 0) hipLaunchKernelGGL((k<0, true>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    if (mode == 1) hipLaunchKernelGGL((k<1, true>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    hipDeviceSynchronize();
+    long long h[8];
+    hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
+    long long rd = 0, mf = 0;
+    for (int i = 0; i < 4; ++i) rd = h[i] > rd ? h[i] : rd;
+    for (int i = 4; i < 8; ++i) mf = h[i] > mf ? h[i] : mf;
+    const double per_iter = (double)rd / iters;
+    printf("%s  4 reading waves + 4 MFMA waves: %8.1f cycles per 24 KiB/wave iteration = %6.1f B/clk/CU (%.1f cycles per read "
+           "instruction and wave); MFMA partner: %.1f cycles per v_mfma_f32_16x16x32_bf16 (16.0 alone)\n", names[mode],
+           per_iter, 4.0 * 24576.0 / per_iter, per_iter / (mode == 0 ? 24.0 : 48.0), (double)mf / (iters * 64.0));
   }
   return 0;
 }
