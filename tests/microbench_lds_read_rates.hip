@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // PARTNER: waves 4-7 (the SIMD partners of waves 0-3) run a saturated v_mfma_f32_16x16x32_bf16 stream instead of reading,
 // as in the anti-phase GEMM slots (4 reading waves next to 4 MFMA waves): bytes per iteration halve, the reported rate is
 // that of the 4 reading waves.
-template <int MODE, bool PARTNER>
+template <int MODE, bool PARTNER, int PRIO_READ = 0, int PRIO_MFMA = 0>
 __global__ __launch_bounds__(512) void k(long long* cyc, unsigned* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512) void k(long long* cyc, unsigned* out, int iter
   u32x2 acc2 = {0, 0};
   __syncthreads();
   if (PARTNER && w >= 4) {
+    __builtin_amdgcn_s_setprio(PRIO_MFMA);
     bf16x8 x, y;
     for (int i = 0; i < 8; ++i) { x[i] = (__bf16)(float)((lane * 7 + i) & 15) * 0.125f; y[i] = (__bf16)(0.5f + 0.01f * i); }
     f32x4 c[8];
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(512) void k(long long* cyc, unsigned* out, int iter
     if (lane == 0 && blockIdx.x == 0) cyc[w] = t1 - t0;
     return;
   }
+  __builtin_amdgcn_s_setprio(PRIO_READ);
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -110,9 +112,13 @@ int main() {
              "cycles of MFMA work per SIMD)\n", names[mode], grid, per_iter, 8.0 * 24576.0 / per_iter);
     }
   }
-  for (int mode = 0; mode < 2; ++mode) {   // 4 reading waves next to 4 MFMA waves (one of each per SIMD)
+  for (int mode = 0; mode < 6; ++mode) {   // 4 reading waves next to 4 MFMA waves (one of each per SIMD); s_setprio variants
     if (mode == 0) hipLaunchKernelGGL((k<0, true>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
     if (mode == 1) hipLaunchKernelGGL((k<1, true>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    if (mode == 2) hipLaunchKernelGGL((k<0, true, 0, 1>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    if (mode == 3) hipLaunchKernelGGL((k<1, true, 0, 1>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    if (mode == 4) hipLaunchKernelGGL((k<0, true, 3, 1>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
+    if (mode == 5) hipLaunchKernelGGL((k<1, true, 3, 1>), dim3(1), dim3(512), 65536, 0, d_cyc, d_out, iters);
     hipDeviceSynchronize();
     long long h[8];
     hipMemcpy(h, d_cyc, 64, hipMemcpyDeviceToHost);
@@ -120,9 +126,10 @@ int main() {
     for (int i = 0; i < 4; ++i) rd = h[i] > rd ? h[i] : rd;
     for (int i = 4; i < 8; ++i) mf = h[i] > mf ? h[i] : mf;
     const double per_iter = (double)rd / iters;
+    printf("[prio read/mfma %s] ", mode < 2 ? "0/0" : (mode < 4 ? "0/1" : "3/1"));
     printf("%s  4 reading waves + 4 MFMA waves: %8.1f cycles per 24 KiB/wave iteration = %6.1f B/clk/CU (%.1f cycles per read "
-           "instruction and wave); MFMA partner: %.1f cycles per v_mfma_f32_16x16x32_bf16 (16.0 alone)\n", names[mode],
-           per_iter, 4.0 * 24576.0 / per_iter, per_iter / (mode == 0 ? 24.0 : 48.0), (double)mf / (iters * 64.0));
+           "instruction and wave); MFMA partner: %.1f cycles per v_mfma_f32_16x16x32_bf16 (16.0 alone)\n", names[mode & 1],
+           per_iter, 4.0 * 24576.0 / per_iter, per_iter / ((mode & 1) == 0 ? 24.0 : 48.0), (double)mf / (iters * 64.0));
   }
   return 0;
 }
