@@ -85,7 +85,10 @@ template <typename TOut>
 static hipError_t ln_fwd_launch(const float* x, const float* gamma, const float* beta, TOut* y, int ldy, float* mean,
                                 float* rstd, int M, int D, float eps, hipStream_t s) {
   int blocks = (M + 3) / 4;
-  if (blocks > 2048) blocks = 2048;  // 8 workgroups per CU; each wave streams its rows with a one-row prefetch
+  // each wave streams its rows (stride = 4 * gridDim) with a one-row prefetch.  Grid size, measured at M = 93 312 (round 3):
+  // 2 048 workgroups (8 per CU, but only 6 are resident at < 80 VGPRs: 1.33 rounds) 135 us = 4.8 TB/s; 1 536 (exactly one
+  // resident round) 115 us; >= 12 288 (a few rows per wave, the dispatcher balances the tail) 111 us = 5.8 TB/s
+  if (blocks > 16384) blocks = 16384;
   dim3 grid(blocks), block(256);
   if (D <= 512)
     hipLaunchKernelGGL((ln_fwd_kernel<TOut, 2>), grid, block, 0, s, x, gamma, beta, y, ldy, mean, rstd, M, D, eps);
