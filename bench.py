@@ -713,29 +713,41 @@ def main():
         print(f"[bench] {value:.1f} images/s, {ms_per_step:.1f} ms/step; measuring kernel roofline + CPU baseline ...",
               file=sys.stderr, flush=True)
         if world == 1:
+            def leg(key, fn, into=None):
+                """Optional legs never cost the headline: a failure is reported in the line instead of killing it."""
+                try:
+                    val = fn()
+                    if val is not None:
+                        (line if into is None else into)[key] = val
+                except Exception as e:   # noqa: BLE001
+                    line.setdefault("leg_errors", {})[key] = f"{type(e).__name__}: {e}"[:300]
+                    torch.cuda.empty_cache()
+
             if args.kernel_reps > 0:
-                line["roofline"] = gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps)
-                if args.mode == "bf16":
-                    line["step_breakdown"] = step_breakdown(pkg, cfg, args.batch, res, max(3, args.kernel_reps // 4),
-                                                            line["roofline"]["per_shape"])
+                leg("roofline", lambda: gemm_kernel_roofline(pkg, cfg, args.batch, res, args.kernel_reps))
+                if args.mode == "bf16" and "roofline" in line:
+                    leg("step_breakdown", lambda: step_breakdown(pkg, cfg, args.batch, res, max(3, args.kernel_reps // 4),
+                                                                 line["roofline"]["per_shape"]))
             if not args.no_secondary and args.mode == "bf16" and args.freeze_below == 0:
-                line["secondary"] = secondary_metrics(pkg, cfg, model, res, dev, args.batch)
+                leg("secondary", lambda: secondary_metrics(pkg, cfg, model, res, dev, args.batch))
             if not args.no_optimizer:
-                line["optimizer_step"] = optimizer_step_roofline(pkg, model, x)
+                leg("optimizer_step", lambda: optimizer_step_roofline(pkg, model, x))
                 if args.freeze_below == 0:
-                    line["train_step_with_optimizer"] = full_train_step(pkg, model, x, steps=args.train_steps)
+                    leg("train_step_with_optimizer", lambda: full_train_step(pkg, model, x, steps=args.train_steps))
             del model
             torch.cuda.empty_cache()
             if not args.no_secondary and args.mode == "bf16" and args.config == "so400m-patch14-384" \
                     and args.freeze_below == 0:
-                line.setdefault("secondary", {})["base_patch16_224_B256"] = base224_metric(pkg, dev)
+                leg("base_patch16_224_B256", lambda: base224_metric(pkg, dev), into=line.setdefault("secondary", {}))
                 torch.cuda.empty_cache()
             if not args.no_cpu_baseline:
-                cb = cpu_baseline(pkg, cfg, res, args.cpu_steps)
-                ref_pooled, x_ref = cb.pop("_pooled_ref"), cb.pop("_x_ref")
-                line["cpu_baseline"] = cb
-                if args.mode == "bf16" and not args.no_secondary:
-                    line["tolerance"] = tolerance_and_strict_mode(pkg, cfg, res, dev, ref_pooled, x_ref)
+                def cpu_leg():
+                    cb = cpu_baseline(pkg, cfg, res, args.cpu_steps)
+                    ref_pooled, x_ref = cb.pop("_pooled_ref"), cb.pop("_x_ref")
+                    line["cpu_baseline"] = cb
+                    if args.mode == "bf16" and not args.no_secondary:
+                        leg("tolerance", lambda: tolerance_and_strict_mode(pkg, cfg, res, dev, ref_pooled, x_ref))
+                leg("cpu_baseline_leg", cpu_leg)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
